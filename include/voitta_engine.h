@@ -1,0 +1,160 @@
+/*
+ * voitta_engine.h — C-ABI of libvoitta_engine.so, the MI355X (gfx950) in-process
+ * indexing-and-retrieval engine that replaces, for voitta-rag's hot path only,
+ *   - sentence-transformers' encode          (reference: src/voitta/services/embedding.py:40-86)
+ *   - fastembed's Qdrant/bm25 sparse vectors  (reference: src/voitta/services/sparse_embedding.py:18-50,
+ *                                              scripts/build_sparse_vectors.py:124,170)
+ *   - the Qdrant client calls on the path     (reference: src/voitta/services/vector_store.py:233-317
+ *                                              upsert, :560-697 search / hybrid fusion, :462-530 filters,
+ *                                              :319-434 deletes)
+ *
+ * The reference has no FFI of its own (it is 100 % Python); these entry points are what a ctypes
+ * binding inside the three service classes would call. Plain pointers and sizes only — no torch,
+ * numpy or C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; vr_last_error() returns a thread-local
+ *     message (the Python side raises RuntimeError with it — reference callers catch broadly:
+ *     src/voitta/services/indexing.py:531-533,561-563).
+ *   - `mem` arguments say where the caller's buffers live: VR_MEM_HOST (pageable host memory,
+ *     e.g. numpy) or VR_MEM_DEVICE (HBM of the engine's device, e.g. a torch-ROCm tensor).
+ *     Output buffers follow the same `mem` unless stated otherwise.
+ *   - row ids are dense int64 indices into the engine's HBM-resident tables, assigned in upsert
+ *     order; the UUID<->row map and the text payload stay in the Python host.
+ *   - thread-safety: one engine may be called from any number of threads; calls are serialised by
+ *     an internal mutex (kernels of one call run back-to-back on the engine's HIP stream).
+ *   - there is NO CPU fallback: creating an engine without a usable gfx950 device fails.
+ */
+#ifndef VOITTA_ENGINE_H
+#define VOITTA_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_ABI_VERSION 1
+
+#define VR_MEM_HOST   0
+#define VR_MEM_DEVICE 1
+
+/* "field absent" marker for the source_created_at / source_modified_at columns
+ * (reference stores the keys only when non-None: vector_store.py:279-282; a point lacking the
+ * key fails a range `must`). */
+#define VR_TS_ABSENT INT64_MIN
+
+/* fusion modes for vr_search_hybrid */
+#define VR_FUSION_MINMAX 0 /* reference behaviour: vector_store.py:659-689 */
+#define VR_FUSION_RRF    1 /* north_star extra mode; no reference oracle */
+
+typedef struct vr_engine vr_engine;
+
+typedef struct vr_config {
+  int32_t struct_size;   /* = sizeof(vr_config) */
+  int32_t device;        /* HIP device ordinal */
+  int32_t dim;           /* dense dimension D (multiple of 16): settings.embedding_dimension, embedding.py:20 */
+  int32_t reserved0;
+  int64_t initial_rows;  /* capacity hint; tables grow by doubling */
+} vr_config;
+
+/* Search-time predicate; restates _build_filter, vector_store.py:462-530. All ids are the
+ * host's dictionary ids of folder_path / index_folder strings (exact string equality in the
+ * reference => integer equality here). Arrays are host pointers and are tiny. */
+typedef struct vr_filter {
+  int32_t struct_size;
+  int32_t n_must_folder_sets;       /* number of `must` any-of sets on folder_path (0..2):
+                                       folder_filter (:476-482) and include_folders (:484-490) */
+  const int32_t* must_folder_ids;   /* concatenated sets */
+  const int32_t* must_folder_off;   /* n_must_folder_sets+1 offsets into must_folder_ids */
+  const int32_t* not_folder_ids;    /* exclude_folders on folder_path (:492-499) */
+  int32_t n_not_folder;
+  int32_t n_not_index_folder;
+  const int32_t* not_index_folder_ids; /* exclude_index_folders on index_folder (:501-508) */
+  int32_t has_date_start;           /* gte (:514-515) */
+  int32_t has_date_end;             /* lte (:516-517) */
+  int64_t date_start;
+  int64_t date_end;
+  int32_t date_field;               /* 0 = source_modified_at (default), 1 = source_created_at (:511-512) */
+  int32_t reserved0;
+} vr_filter;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int  vr_abi_version(void);
+const char* vr_last_error(void);
+int  vr_engine_create(const vr_config* cfg, vr_engine** out);
+void vr_engine_destroy(vr_engine* e);
+/* block until every kernel queued by previous calls has finished (for timing) */
+int  vr_sync(vr_engine* e);
+/* the engine's hipStream_t, as an opaque pointer (bench.py records HIP events on it) */
+void* vr_stream(vr_engine* e);
+
+/* ---- index: replaces VectorStoreService.store_chunks' client.upsert (vector_store.py:291-313)
+ * and the Qdrant-side cosine normalisation on insert (SURVEY.md a10 [EXT]). ------------------- */
+/* dense   : n x D f32 row-major
+ * sp_off  : n+1 CSR offsets, sp_idx/sp_val : BM25 (token id, tf weight); NULL sp_off => rows carry
+ *           no sparse vector (vector_store.py:299-300)
+ * folder_id / index_folder_id : per-row dictionary ids (NULL => 0)
+ * created / modified : per-row epochs or VR_TS_ABSENT (NULL => all absent)
+ * out_first_row : rows [first, first+n) were assigned */
+int vr_upsert(vr_engine* e, int64_t n, int mem,
+              const float* dense,
+              const int64_t* sp_off, const int32_t* sp_idx, const float* sp_val,
+              const int32_t* folder_id, const int32_t* index_folder_id,
+              const int64_t* created, const int64_t* modified,
+              int64_t* out_first_row);
+
+/* tombstone rows (host pointer); replaces the filtered client.delete of vector_store.py:340-352,
+ * :378-390,:419-431 once the host has resolved the filter to rows. Already-dead rows are ignored;
+ * document frequencies and the sparse point count are decremented. */
+int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
+
+/* n_rows = rows ever assigned, n_live = not tombstoned (get_collection_info, vector_store.py:699-710) */
+int vr_count(vr_engine* e, int64_t* n_rows, int64_t* n_live);
+
+/* read back stored (normalised) dense rows — scroll(with_vectors=True) of
+ * scripts/build_sparse_vectors.py:140-146. out: n x D f32 (host). */
+int vr_get_dense(vr_engine* e, const int64_t* rows, int64_t n, float* out);
+
+/* document frequency of token ids and the sparse point count N (Qdrant Modifier.IDF statistics,
+ * vector_store.py:95-99). ids/out_df are host pointers. */
+int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df, int64_t* out_n_points);
+
+/* ---- search: replaces client.query_points (vector_store.py:612-617, :640-656) ------------- */
+/* q : nq x D f32 (`mem`); results (host): rows[nq*k] (-1 padded), scores[nq*k], counts[nq].
+ * Exact f32 brute force over live rows that pass `filter` (NULL = none), score = k-ordered f32
+ * fma chain of q_hat . x_hat, ties broken by the lower row id. */
+int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k,
+                    const vr_filter* filter,
+                    int64_t* rows, float* scores, int32_t* counts);
+
+/* one sparse query (host pointers): score(d) = sum_t (q_t * idf(t)) * d_t over shared terms in
+ * ascending token-id order, idf(t) = ln(1 + (N - df_t + 0.5)/(df_t + 0.5)); rows sharing no
+ * term are not returned. */
+int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int32_t nnz,
+                     int32_t k, const vr_filter* filter,
+                     int64_t* rows, float* scores, int32_t* count);
+
+/* hybrid: restates VectorStoreService._hybrid_search (vector_store.py:621-697): dense and sparse
+ * top-(3*limit), min-max normalisation, (1-w)*d + w*s over the id union, top-`limit`.
+ * out_scores are the fused scores as f64 (Python floats in the reference, :680,:694).
+ * out_from_dense[i] = 1 when the row was in the dense list (:682-685). */
+int vr_search_hybrid(vr_engine* e, const float* q, int mem,
+                     const int32_t* q_idx, const float* q_val, int32_t nnz,
+                     int32_t limit, double sparse_weight, int32_t fusion,
+                     const vr_filter* filter,
+                     int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
+
+/* The fusion arithmetic alone (host, no GPU): what vector_store.py:659-697 does to two result
+ * lists. Exposed so the reference's own two-list code path can be checked in isolation.
+ * json_scores != 0 reproduces the REST transport of the reference (f32 score -> shortest decimal
+ * -> Python float) instead of exact f32->f64 widening. */
+int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd,
+                   const int64_t* s_rows, const float* s_scores, int32_t ns,
+                   int32_t limit, double sparse_weight, int32_t json_scores,
+                   int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOITTA_ENGINE_H */

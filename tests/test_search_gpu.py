@@ -1,0 +1,196 @@
+"""Parity of the HIP store/search path (through the C-ABI) against the CPU oracle, bit for bit:
+stored vectors, dense scores, sparse scores, ranked row ids, fused scores.
+Reference behaviour restated: src/voitta/services/vector_store.py:233-317 (store), :560-697
+(search / hybrid), :462-530 (filters), :319-355 (delete)."""
+import numpy as np
+import pytest
+
+from oracle import core as ocore
+from oracle import fusion as ofus
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(dim, **kw):
+    from voitta_rag_amd import Engine
+
+    return Engine(dim, **kw)
+
+
+def _corpus(rng, n, dim):
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[::7] = ocore.cosine_preprocess(x[::7])  # already unit length -> stored untouched
+    if n > 5:
+        x[5] = 0.0  # zero vector -> stored untouched
+    x[1::11] *= 37.5
+    return x
+
+
+def _sparse_rows(rng, n, vocab=500, lo=0, hi=40):
+    rows = []
+    for _ in range(n):
+        m = int(rng.integers(lo, hi + 1))
+        ids = rng.choice(vocab, size=m, replace=False).astype(np.int32) * 7919 + 13
+        vals = rng.uniform(0.2, 2.2, size=m).astype(np.float32)
+        rows.append((ids, vals))
+    return rows
+
+
+@pytest.mark.parametrize("dim,n", [(384, 3001), (768, 1000), (1024, 257), (16, 40)])
+def test_store_and_dense_search_bit_exact(gpu, dim, n):
+    rng = np.random.default_rng(dim + n)
+    x = _corpus(rng, n, dim)
+    e = _engine(dim)
+    # several unaligned batches
+    cuts = [0, 1, 18, 100, n // 2, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert e.upsert(x[a:b]) == a
+    assert e.count() == (n, n)
+    want_x = ocore.cosine_preprocess(x)
+    got_x = e.get_dense(np.arange(n))
+    assert np.array_equal(got_x.view(np.uint32), want_x.view(np.uint32))
+
+    q = rng.standard_normal((21, dim)).astype(np.float32)
+    q[3] = x[17]  # exact duplicate of a stored row
+    want_scores = ocore.dense_scores(ocore.cosine_preprocess(q), want_x)
+    for k in (1, 10, 30):
+        got = e.search_dense(q, k)
+        for i in range(q.shape[0]):
+            wr, ws = ocore.topk(want_scores[i], k)
+            assert np.array_equal(got[i][0], wr), (dim, n, k, i)
+            assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32))
+    e.close()
+
+
+def test_ties_resolve_to_lower_row(gpu):
+    dim = 64
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((50, dim)).astype(np.float32)
+    x = np.concatenate([base, base[:20]])  # rows 50..69 duplicate rows 0..19
+    e = _engine(dim)
+    e.upsert(x)
+    rows, scores = e.search_dense(base[7:8], 4)[0]
+    assert rows[0] == 7 and rows[1] == 57 and scores[0] == scores[1]
+    e.close()
+
+
+def test_delete_filter_and_counts(gpu):
+    dim, n = 128, 2000
+    rng = np.random.default_rng(11)
+    x = _corpus(rng, n, dim)
+    folder = rng.integers(0, 9, size=n).astype(np.int32)
+    ifolder = rng.integers(0, 4, size=n).astype(np.int32)
+    from voitta_rag_amd import SearchFilter
+    from voitta_rag_amd.engine import VR_TS_ABSENT
+
+    modified = rng.integers(1_600_000_000, 1_700_000_000, size=n).astype(np.int64)
+    modified[::5] = VR_TS_ABSENT
+    created = rng.integers(1_500_000_000, 1_600_000_000, size=n).astype(np.int64)
+    e = _engine(dim)
+    e.upsert(x, folder_ids=folder, index_folder_ids=ifolder, created=created, modified=modified)
+    dead = rng.choice(n, size=300, replace=False)
+    e.delete_rows(np.concatenate([dead, dead[:10]]))  # duplicates ignored
+    e.delete_rows(dead[:5])  # already dead ignored
+    assert e.count() == (n, n - 300)
+    live = np.ones(n, np.uint8)
+    live[dead] = 0
+    xh = ocore.cosine_preprocess(x)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    sc = ocore.dense_scores(ocore.cosine_preprocess(q), xh)
+
+    cases = [
+        (SearchFilter(), live.astype(bool)),
+        (SearchFilter(folder_filter=3), live.astype(bool) & (folder == 3)),
+        (SearchFilter(include_folders=[1, 2, 8, 77]), live.astype(bool) & np.isin(folder, [1, 2, 8])),
+        (SearchFilter(folder_filter=2, include_folders=[1, 2]), live.astype(bool) & (folder == 2)),
+        (SearchFilter(folder_filter=2, include_folders=[1]), np.zeros(n, bool)),
+        (SearchFilter(exclude_folders=[0, 4], exclude_index_folders=[1]),
+         live.astype(bool) & ~np.isin(folder, [0, 4]) & (ifolder != 1)),
+        (SearchFilter(date_start=1_650_000_000), live.astype(bool) & (modified != VR_TS_ABSENT) & (modified >= 1_650_000_000)),
+        (SearchFilter(date_start=1_620_000_000, date_end=1_660_000_000),
+         live.astype(bool) & (modified != VR_TS_ABSENT) & (modified >= 1_620_000_000) & (modified <= 1_660_000_000)),
+        (SearchFilter(date_end=1_550_000_000, date_field="created"), live.astype(bool) & (created <= 1_550_000_000)),
+        (SearchFilter(date_end=1_650_000_000, date_field="bogus"),
+         live.astype(bool) & (modified != VR_TS_ABSENT) & (modified <= 1_650_000_000)),
+    ]
+    for flt, mask in cases:
+        got = e.search_dense(q, 25, flt)
+        for i in range(3):
+            wr, ws = ocore.topk(sc[i], 25, mask.astype(np.uint8))
+            assert np.array_equal(got[i][0], wr), flt
+            assert np.array_equal(got[i][1], ws)
+    e.close()
+
+
+def test_sparse_and_hybrid_bit_exact(gpu):
+    dim, n = 64, 1500
+    rng = np.random.default_rng(5)
+    x = _corpus(rng, n, dim)
+    sp = _sparse_rows(rng, n)
+    e = _engine(dim)
+    cuts = [0, 70, 200, 1000, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.upsert(x[a:b], sparse=sp[a:b])
+    xh = ocore.cosine_preprocess(x)
+    df_want, n_points = ocore.document_frequencies(sp)
+    some = np.array(sorted(df_want)[:50] + [999_999_999], np.int32)
+    df_got, n_got = e.sparse_stats(some)
+    assert n_got == n_points == n
+    assert [int(v) for v in df_got] == [df_want.get(int(t), 0) for t in some]
+
+    live = np.ones(n, bool)
+    for round_ in range(2):
+        for trial in range(12):
+            m = int(rng.integers(1, 9))
+            qi = (rng.choice(500, size=m, replace=False).astype(np.int32) * 7919 + 13)
+            if trial == 0:
+                qi[0] = 5  # a token no document has
+            qv = np.ones(m, np.float32)
+            want = ocore.sparse_scores(sp, qi, qv, live)
+            for k in (10, 30):
+                wr, ws = ocore.topk(want, k, live.astype(np.uint8))
+                gr, gs = e.search_sparse(qi, qv, k)
+                assert np.array_equal(gr, wr), (round_, trial, k)
+                assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+            # hybrid, reference defaults: limit 10, prefetch 30, sparse_weight 0.1
+            q = rng.standard_normal(dim).astype(np.float32)
+            dsc = ocore.dense_scores(ocore.cosine_preprocess(q[None]), xh)[0]
+            for limit, w in ((10, 0.1), (20, 0.5), (3, 1.0), (5, 0.0)):
+                dr, ds = ocore.topk(dsc, 3 * limit, live.astype(np.uint8))
+                sr, ss = ocore.topk(want, 3 * limit, live.astype(np.uint8))
+                fused = ofus.hybrid_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())),
+                                         limit, w, "json")
+                rows, scores, fd = e.search_hybrid(q, qi, qv, limit, w)
+                assert rows.tolist() == [r for r, _, _ in fused]
+                assert scores.tolist() == [s for _, s, _ in fused]
+                assert fd.astype(bool).tolist() == [f for _, _, f in fused]
+        # second round: after deletes the document frequencies and N must follow
+        dead = rng.choice(n, size=400, replace=False)
+        e.delete_rows(dead)
+        live[dead] = False
+    e.close()
+
+
+def test_rows_without_sparse_vectors_and_empty_engine(gpu):
+    dim = 32
+    rng = np.random.default_rng(9)
+    e = _engine(dim)
+    assert e.search_dense(np.ones((2, dim), np.float32), 5) == [] or all(len(r) == 0 for r, _ in e.search_dense(np.ones((2, dim), np.float32), 5))
+    r, s = e.search_sparse([1, 2], [1.0, 1.0], 5)
+    assert len(r) == 0
+    x = _corpus(rng, 130, dim)
+    sp = _sparse_rows(rng, 130, lo=0, hi=6)
+    e.upsert(x[:65])  # no sparse vectors at all
+    e.upsert(x[65:], sparse=sp[65:])
+    rows_sp = [None] * 65 + sp[65:]
+    qi = sp[70][0][:2] if len(sp[70][0]) >= 2 else np.array([13], np.int32)
+    qv = np.ones(len(qi), np.float32)
+    want = ocore.sparse_scores(rows_sp, qi, qv)
+    wr, ws = ocore.topk(want, 10)
+    gr, gs = e.search_sparse(qi, qv, 10)
+    assert np.array_equal(gr, wr) and np.array_equal(gs, ws)
+    assert (gr >= 65).all()
+    # hybrid with an empty sparse query term list degrades to dense candidates only
+    rows, scores, fd = e.search_hybrid(x[3], [], [], 5, 0.1)
+    assert rows[0] == 3 and fd.all()
+    e.close()

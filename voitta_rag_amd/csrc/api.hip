@@ -1,0 +1,495 @@
+// extern "C" surface of libvoitta_engine.so (include/voitta_engine.h): engine lifecycle, the
+// store (upsert / delete / count / read-back) and the three searches. Every entry point cites
+// the reference call it stands in for in the header; this file only sequences kernels on the
+// engine's stream and moves small results back to the host.
+
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <climits>
+
+namespace vr {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int64_t n) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+static int ensure_rows(vr_engine* e, int64_t need) {
+  if (need <= e->cap_rows) return 0;
+  int64_t ncap = e->cap_rows ? e->cap_rows : 1024;
+  while (ncap < need) ncap *= 2;
+  ncap = (ncap + 63) / 64 * 64;
+  const int64_t keep_rows = e->n_rows;
+  const int64_t keep_tiles = (keep_rows + kTileRows - 1) / kTileRows;
+  VR_TRY(e->corpus.grow(ncap * e->dim, keep_tiles * kTileRows * e->dim, e->stream));
+  VR_TRY(e->live.grow(ncap, keep_rows, e->stream));
+  VR_TRY(e->folder.grow(ncap, keep_rows, e->stream));
+  VR_TRY(e->index_folder.grow(ncap, keep_rows, e->stream));
+  VR_TRY(e->created.grow(ncap, keep_rows, e->stream));
+  VR_TRY(e->modified.grow(ncap, keep_rows, e->stream));
+  VR_TRY(e->row_slice.grow(ncap, keep_rows, e->stream));
+  // DevArray rounds to powers of two; use the smallest capacity everywhere
+  ncap = std::min({e->live.cap, e->folder.cap, e->index_folder.cap, e->created.cap,
+                   e->modified.cap, e->row_slice.cap, e->corpus.cap / e->dim});
+  ncap = ncap / 64 * 64;
+  VR_HIP(hipMemsetAsync(e->live.p + keep_rows, 0, static_cast<size_t>(ncap - keep_rows), e->stream));
+  e->cap_rows = ncap;
+  return 0;
+}
+
+static int64_t decode_keys(const uint64_t* keys, int k, int64_t* rows, float* scores) {
+  int64_t n = 0;
+  for (int i = 0; i < k; ++i) {
+    uint64_t key = keys[i];
+    if (key == 0) {
+      rows[i] = -1;
+      scores[i] = 0.0f;
+      continue;
+    }
+    uint32_t hi = static_cast<uint32_t>(key >> 32);
+    uint32_t u = (hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi;
+    float s;
+    memcpy(&s, &u, 4);
+    rows[i] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(key & 0xFFFFFFFFu));
+    scores[i] = s;
+    ++n;
+  }
+  return n;
+}
+
+constexpr size_t kPinnedBytes = 1 << 20;
+constexpr size_t kPinnedResultOff = 8192;
+
+static int check_engine(vr_engine* e) {
+  VR_CHECK(e != nullptr, "null engine");
+  VR_HIP(hipSetDevice(e->device));
+  return 0;
+}
+
+static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k,
+                              const uint8_t* mask, uint64_t* host_keys /* pinned, nq*k */) {
+  VR_TRY(dense_make_query_image(e, q_dev, nq));
+  VR_TRY(dense_scores(e, nq, mask));
+  const uint64_t* keys = nullptr;
+  VR_TRY(topk_select(e, e->scores.p, e->cap_rows, e->n_rows, nq, k, &keys));
+  VR_HIP(hipMemcpyAsync(host_keys, keys, sizeof(uint64_t) * static_cast<size_t>(nq) * k,
+                        hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+
+static int search_sparse_block(vr_engine* e, const int32_t* q_idx, const float* q_val, int nnz, int k,
+                               const uint8_t* mask, uint64_t* host_keys /* pinned, k */) {
+  VR_TRY(sparse_scores(e, q_idx, q_val, nnz, mask));
+  const uint64_t* keys = nullptr;
+  VR_TRY(topk_select(e, e->sp_scores.p, e->cap_rows, e->n_rows, 1, k, &keys));
+  VR_HIP(hipMemcpyAsync(host_keys, keys, sizeof(uint64_t) * static_cast<size_t>(k),
+                        hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+
+}  // namespace vr
+
+using namespace vr;
+
+extern "C" {
+
+int vr_abi_version(void) { return VR_ABI_VERSION; }
+
+const char* vr_last_error(void) { return g_last_error.c_str(); }
+
+int vr_engine_create(const vr_config* cfg, vr_engine** out) {
+  VR_CHECK(cfg && out, "null argument");
+  VR_CHECK(cfg->struct_size == static_cast<int32_t>(sizeof(vr_config)), "vr_config size mismatch");
+  VR_CHECK(cfg->dim > 0 && cfg->dim % 16 == 0, "dim %d must be a positive multiple of 16", cfg->dim);
+  int n_dev = 0;
+  hipError_t err = hipGetDeviceCount(&n_dev);
+  VR_CHECK(err == hipSuccess && n_dev > 0,
+           "no HIP device available (%s): libvoitta_engine has no CPU fallback",
+           err == hipSuccess ? "device count 0" : hipGetErrorString(err));
+  VR_CHECK(cfg->device >= 0 && cfg->device < n_dev, "device %d out of range (0..%d)", cfg->device,
+           n_dev - 1);
+  hipDeviceProp_t prop;
+  VR_HIP(hipGetDeviceProperties(&prop, cfg->device));
+  VR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+           "device %d is %s; this library carries gfx950 (MI355X) code objects only", cfg->device,
+           prop.gcnArchName);
+  VR_HIP(hipSetDevice(cfg->device));
+  vr_engine* e = new vr_engine();
+  e->device = cfg->device;
+  e->dim = cfg->dim;
+  e->kblocks = cfg->dim / kTileK;
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    delete e;
+    return -1;
+  }
+  if (hipHostMalloc(&e->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed");
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+    return -1;
+  }
+  e->pinned_bytes = kPinnedBytes;
+  int64_t init = cfg->initial_rows > 0 ? cfg->initial_rows : 1024;
+  if (ensure_rows(e, init) != 0) {
+    vr_engine_destroy(e);
+    return -1;
+  }
+  *out = e;
+  return 0;
+}
+
+void vr_engine_destroy(vr_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  e->corpus.release();
+  e->live.release();
+  e->folder.release();
+  e->index_folder.release();
+  e->created.release();
+  e->modified.release();
+  e->row_slice.release();
+  e->slices.release();
+  e->sp_idx.release();
+  e->sp_val.release();
+  e->df_keys.release();
+  e->df_cnt.release();
+  if (e->df_distinct) (void)hipFree(e->df_distinct);
+  e->stage_dense.release();
+  e->stage_len.release();
+  e->stage_off.release();
+  e->stage_idx.release();
+  e->stage_val.release();
+  e->stage_i32a.release();
+  e->stage_i32b.release();
+  e->stage_i64a.release();
+  e->stage_i64b.release();
+  e->q_tiled.release();
+  e->scores.release();
+  e->sp_scores.release();
+  e->mask.release();
+  e->pass_folder.release();
+  e->pass_ifolder.release();
+  e->cand_a.release();
+  e->cand_b.release();
+  e->q_ids.release();
+  e->q_w.release();
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int vr_sync(vr_engine* e) {
+  VR_TRY(check_engine(e));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+void* vr_stream(vr_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
+              const int32_t* sp_idx, const float* sp_val, const int32_t* folder_id,
+              const int32_t* index_folder_id, const int64_t* created, const int64_t* modified,
+              int64_t* out_first_row) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n >= 0, "negative row count");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  const int64_t first = e->n_rows;
+  if (out_first_row) *out_first_row = first;
+  if (n == 0) return 0;
+  VR_CHECK(dense != nullptr, "null dense");
+  VR_CHECK(first + n < (int64_t{1} << 32), "row id space exhausted");
+  VR_TRY(ensure_rows(e, first + n));
+
+  const float* x_dev = dense;
+  if (mem == VR_MEM_HOST) {
+    VR_TRY(e->stage_dense.grow(n * e->dim, 0, e->stream));
+    VR_HIP(hipMemcpyAsync(e->stage_dense.p, dense, sizeof(float) * static_cast<size_t>(n * e->dim),
+                          hipMemcpyHostToDevice, e->stream));
+    x_dev = e->stage_dense.p;
+  }
+  VR_TRY(dense_store_rows(e, x_dev, n, first));
+
+  // payload columns are always host arrays (they come from Python metadata)
+  if (folder_id) {
+    for (int64_t i = 0; i < n; ++i) {
+      VR_CHECK(folder_id[i] >= 0, "negative folder id");
+      e->max_folder_id = std::max(e->max_folder_id, folder_id[i]);
+    }
+    VR_HIP(hipMemcpyAsync(e->folder.p + first, folder_id, sizeof(int32_t) * static_cast<size_t>(n),
+                          hipMemcpyHostToDevice, e->stream));
+  } else {
+    e->max_folder_id = std::max(e->max_folder_id, 0);
+    VR_HIP(hipMemsetAsync(e->folder.p + first, 0, sizeof(int32_t) * static_cast<size_t>(n), e->stream));
+  }
+  if (index_folder_id) {
+    for (int64_t i = 0; i < n; ++i) {
+      VR_CHECK(index_folder_id[i] >= 0, "negative index-folder id");
+      e->max_index_folder_id = std::max(e->max_index_folder_id, index_folder_id[i]);
+    }
+    VR_HIP(hipMemcpyAsync(e->index_folder.p + first, index_folder_id,
+                          sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, e->stream));
+  } else {
+    e->max_index_folder_id = std::max(e->max_index_folder_id, 0);
+    VR_HIP(hipMemsetAsync(e->index_folder.p + first, 0, sizeof(int32_t) * static_cast<size_t>(n),
+                          e->stream));
+  }
+  const unsigned fill_blocks = static_cast<unsigned>((n + 255) / 256);
+  if (created)
+    VR_HIP(hipMemcpyAsync(e->created.p + first, created, sizeof(int64_t) * static_cast<size_t>(n),
+                          hipMemcpyHostToDevice, e->stream));
+  else
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(fill_blocks), dim3(256), 0, e->stream,
+                       e->created.p + first, static_cast<int64_t>(VR_TS_ABSENT), n);
+  if (modified)
+    VR_HIP(hipMemcpyAsync(e->modified.p + first, modified, sizeof(int64_t) * static_cast<size_t>(n),
+                          hipMemcpyHostToDevice, e->stream));
+  else
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(fill_blocks), dim3(256), 0, e->stream,
+                       e->modified.p + first, static_cast<int64_t>(VR_TS_ABSENT), n);
+  VR_HIP(hipMemsetAsync(e->live.p + first, 1, static_cast<size_t>(n), e->stream));
+  VR_HIP(hipMemsetAsync(e->row_slice.p + first, 0xFF, sizeof(int32_t) * static_cast<size_t>(n),
+                        e->stream));
+
+  if (sp_off) {
+    VR_CHECK(sp_idx && sp_val, "sparse offsets without indices/values");
+    if (mem == VR_MEM_HOST) {
+      const int64_t nnz = sp_off[n];
+      VR_CHECK(sp_off[0] == 0 && nnz >= 0, "bad sparse offsets");
+      // sort every row by token id (Qdrant sorts sparse vectors by index on ingestion [EXT])
+      std::vector<int32_t> idx(sp_idx, sp_idx + nnz);
+      std::vector<float> val(sp_val, sp_val + nnz);
+      std::vector<std::pair<int32_t, float>> tmp;
+      for (int64_t r = 0; r < n; ++r) {
+        int64_t b = sp_off[r], en = sp_off[r + 1];
+        VR_CHECK(en >= b, "sparse offsets must be non-decreasing");
+        bool sorted = true;
+        for (int64_t j = b + 1; j < en; ++j) sorted = sorted && idx[static_cast<size_t>(j - 1)] < idx[static_cast<size_t>(j)];
+        for (int64_t j = b; j < en; ++j) VR_CHECK(idx[static_cast<size_t>(j)] >= 0, "negative token id");
+        if (sorted) continue;
+        tmp.clear();
+        for (int64_t j = b; j < en; ++j) tmp.emplace_back(idx[static_cast<size_t>(j)], val[static_cast<size_t>(j)]);
+        std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+        for (int64_t j = b; j < en; ++j) {
+          idx[static_cast<size_t>(j)] = tmp[static_cast<size_t>(j - b)].first;
+          val[static_cast<size_t>(j)] = tmp[static_cast<size_t>(j - b)].second;
+        }
+      }
+      VR_TRY(e->stage_off.grow(n + 1, 0, e->stream));
+      VR_TRY(e->stage_idx.grow(std::max<int64_t>(nnz, 1), 0, e->stream));
+      VR_TRY(e->stage_val.grow(std::max<int64_t>(nnz, 1), 0, e->stream));
+      VR_HIP(hipMemcpyAsync(e->stage_off.p, sp_off, sizeof(int64_t) * static_cast<size_t>(n + 1),
+                            hipMemcpyHostToDevice, e->stream));
+      if (nnz > 0) {
+        VR_HIP(hipMemcpyAsync(e->stage_idx.p, idx.data(), sizeof(int32_t) * static_cast<size_t>(nnz),
+                              hipMemcpyHostToDevice, e->stream));
+        VR_HIP(hipMemcpyAsync(e->stage_val.p, val.data(), sizeof(float) * static_cast<size_t>(nnz),
+                              hipMemcpyHostToDevice, e->stream));
+      }
+      VR_HIP(hipStreamSynchronize(e->stream));  // idx/val vectors die at scope end
+      VR_TRY(sparse_append(e, n, first, sp_off, e->stage_off.p, e->stage_idx.p, e->stage_val.p));
+    } else {
+      std::vector<int64_t> off_host(static_cast<size_t>(n + 1));
+      VR_HIP(hipMemcpyAsync(off_host.data(), sp_off, sizeof(int64_t) * static_cast<size_t>(n + 1),
+                            hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));
+      VR_TRY(sparse_append(e, n, first, off_host.data(), sp_off, sp_idx, sp_val));
+    }
+  }
+  VR_HIP(hipGetLastError());
+  // caller-owned host arrays must not be read after we return
+  if (mem == VR_MEM_HOST || folder_id || index_folder_id || created || modified)
+    VR_HIP(hipStreamSynchronize(e->stream));
+  e->n_rows += n;
+  e->n_live += n;
+  return 0;
+}
+
+int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n >= 0 && (n == 0 || rows), "bad arguments");
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lock(e->mu);
+  std::vector<int64_t> uniq(rows, rows + n);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  const int64_t m = static_cast<int64_t>(uniq.size());
+  VR_TRY(e->stage_i64a.grow(m, 0, e->stream));
+  VR_HIP(hipMemcpyAsync(e->stage_i64a.p, uniq.data(), sizeof(int64_t) * static_cast<size_t>(m),
+                        hipMemcpyHostToDevice, e->stream));
+  int64_t deleted = 0, sparse_deleted = 0;
+  VR_TRY(sparse_delete_rows(e, e->stage_i64a.p, m, &deleted, &sparse_deleted));
+  e->n_live -= deleted;
+  e->n_sparse_points -= sparse_deleted;
+  return 0;
+}
+
+int vr_count(vr_engine* e, int64_t* n_rows, int64_t* n_live) {
+  VR_CHECK(e != nullptr, "null engine");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (n_rows) *n_rows = e->n_rows;
+  if (n_live) *n_live = e->n_live;
+  return 0;
+}
+
+int vr_get_dense(vr_engine* e, const int64_t* rows, int64_t n, float* out) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n >= 0 && (n == 0 || (rows && out)), "bad arguments");
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lock(e->mu);
+  for (int64_t i = 0; i < n; ++i)
+    VR_CHECK(rows[i] >= 0 && rows[i] < e->n_rows, "row %lld out of range", static_cast<long long>(rows[i]));
+  VR_TRY(e->stage_i64a.grow(n, 0, e->stream));
+  VR_TRY(e->stage_dense.grow(n * e->dim, 0, e->stream));
+  VR_HIP(hipMemcpyAsync(e->stage_i64a.p, rows, sizeof(int64_t) * static_cast<size_t>(n),
+                        hipMemcpyHostToDevice, e->stream));
+  VR_TRY(dense_read_rows(e, e->stage_i64a.p, n, e->stage_dense.p));
+  VR_HIP(hipMemcpyAsync(out, e->stage_dense.p, sizeof(float) * static_cast<size_t>(n * e->dim),
+                        hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df, int64_t* out_n_points) {
+  VR_TRY(check_engine(e));
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (out_n_points) *out_n_points = e->n_sparse_points;
+  if (n > 0) {
+    VR_CHECK(ids && out_df, "null argument");
+    if (e->df_cap == 0) {
+      for (int i = 0; i < n; ++i) out_df[i] = 0;
+    } else {
+      VR_TRY(sparse_lookup_df(e, ids, n, out_df));
+    }
+  }
+  return 0;
+}
+
+int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k,
+                    const vr_filter* filter, int64_t* rows, float* scores, int32_t* counts) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && rows && scores && nq >= 1, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (e->n_rows == 0) {
+    for (int64_t i = 0; i < static_cast<int64_t>(nq) * k; ++i) {
+      rows[i] = -1;
+      scores[i] = 0.0f;
+    }
+    if (counts)
+      for (int i = 0; i < nq; ++i) counts[i] = 0;
+    return 0;
+  }
+  const uint8_t* mask = nullptr;
+  VR_TRY(filter_build_mask(e, filter, &mask));
+  uint64_t* host_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
+  for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
+    const int nb = std::min(kQueryBlock, nq - q0);
+    const float* q_dev = q + static_cast<int64_t>(q0) * e->dim;
+    if (mem == VR_MEM_HOST) {
+      VR_TRY(e->stage_dense.grow(static_cast<int64_t>(kQueryBlock) * e->dim, 0, e->stream));
+      VR_HIP(hipMemcpyAsync(e->stage_dense.p, q_dev, sizeof(float) * static_cast<size_t>(nb) * e->dim,
+                            hipMemcpyHostToDevice, e->stream));
+      q_dev = e->stage_dense.p;
+    }
+    VR_TRY(search_dense_block(e, q_dev, nb, k, mask, host_keys));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < nb; ++i) {
+      int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k,
+                              rows + static_cast<int64_t>(q0 + i) * k,
+                              scores + static_cast<int64_t>(q0 + i) * k);
+      if (counts) counts[q0 + i] = static_cast<int32_t>(c);
+    }
+  }
+  return 0;
+}
+
+int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int32_t nnz, int32_t k,
+                     const vr_filter* filter, int64_t* rows, float* scores, int32_t* count) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(rows && scores && count, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  std::lock_guard<std::mutex> lock(e->mu);
+  *count = 0;
+  for (int i = 0; i < k; ++i) {
+    rows[i] = -1;
+    scores[i] = 0.0f;
+  }
+  if (e->n_rows == 0 || e->n_slices_dev == 0 || nnz <= 0) return 0;
+  VR_CHECK(q_idx && q_val, "null sparse query");
+  const uint8_t* mask = nullptr;
+  VR_TRY(filter_build_mask(e, filter, &mask));
+  uint64_t* host_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
+  VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, host_keys));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  *count = static_cast<int32_t>(decode_keys(host_keys, k, rows, scores));
+  return 0;
+}
+
+int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx, const float* q_val,
+                     int32_t nnz, int32_t limit, double sparse_weight, int32_t fusion,
+                     const vr_filter* filter, int64_t* out_rows, double* out_scores,
+                     int32_t* out_from_dense, int32_t* out_count) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && out_rows && out_scores && out_count, "bad arguments");
+  VR_CHECK(limit >= 1 && limit * 3 <= kMaxK, "limit = %d not in 1..%d", limit, kMaxK / 3);
+  VR_CHECK(fusion == VR_FUSION_MINMAX || fusion == VR_FUSION_RRF, "unknown fusion %d", fusion);
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  *out_count = 0;
+  if (e->n_rows == 0) return 0;
+  const int k = limit * 3;  // prefetch_limit, vector_store.py:636
+  const uint8_t* mask = nullptr;
+  VR_TRY(filter_build_mask(e, filter, &mask));
+  uint64_t* dense_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
+  uint64_t* sparse_keys = dense_keys + kMaxK;
+  const float* q_dev = q;
+  if (mem == VR_MEM_HOST) {
+    VR_TRY(e->stage_dense.grow(static_cast<int64_t>(kQueryBlock) * e->dim, 0, e->stream));
+    VR_HIP(hipMemcpyAsync(e->stage_dense.p, q, sizeof(float) * static_cast<size_t>(e->dim),
+                          hipMemcpyHostToDevice, e->stream));
+    q_dev = e->stage_dense.p;
+  }
+  VR_TRY(search_dense_block(e, q_dev, 1, k, mask, dense_keys));
+  const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
+  if (have_sparse) {
+    VR_CHECK(q_idx && q_val, "null sparse query");
+    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, sparse_keys));
+  }
+  VR_HIP(hipStreamSynchronize(e->stream));
+  int64_t d_rows[kMaxK], s_rows[kMaxK];
+  float d_scores[kMaxK], s_scores[kMaxK];
+  int nd = static_cast<int>(decode_keys(dense_keys, k, d_rows, d_scores));
+  int ns = have_sparse ? static_cast<int>(decode_keys(sparse_keys, k, s_rows, s_scores)) : 0;
+  if (fusion == VR_FUSION_MINMAX)
+    return fuse_minmax(d_rows, d_scores, nd, s_rows, s_scores, ns, limit, sparse_weight, 1, out_rows,
+                       out_scores, out_from_dense, out_count);
+  return fuse_rrf(d_rows, nd, s_rows, ns, limit, sparse_weight, out_rows, out_scores, out_from_dense,
+                  out_count);
+}
+
+int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd, const int64_t* s_rows,
+                   const float* s_scores, int32_t ns, int32_t limit, double sparse_weight,
+                   int32_t json_scores, int64_t* out_rows, double* out_scores,
+                   int32_t* out_from_dense, int32_t* out_count) {
+  VR_CHECK(nd >= 0 && ns >= 0 && out_rows && out_scores && out_count, "bad arguments");
+  return fuse_minmax(d_rows, d_scores, nd, s_rows, s_scores, ns, limit, sparse_weight, json_scores,
+                     out_rows, out_scores, out_from_dense, out_count);
+}
+
+}  // extern "C"

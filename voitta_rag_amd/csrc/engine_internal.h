@@ -1,0 +1,195 @@
+// Internal declarations shared by the translation units of libvoitta_engine.so.
+// Nothing here is part of the ABI; the ABI is include/voitta_engine.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "voitta_engine.h"
+
+namespace vr {
+
+void set_error(const char* fmt, ...);
+
+#define VR_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t _err = (call);                                                               \
+    if (_err != hipSuccess) {                                                               \
+      ::vr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), __FILE__,    \
+                      __LINE__);                                                            \
+      return -1;                                                                            \
+    }                                                                                       \
+  } while (0)
+
+#define VR_CHECK(cond, ...)          \
+  do {                               \
+    if (!(cond)) {                   \
+      ::vr::set_error(__VA_ARGS__);  \
+      return -1;                     \
+    }                                \
+  } while (0)
+
+#define VR_TRY(expr)        \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// Growable device array. grow() keeps the first `keep` elements.
+template <class T>
+struct DevArray {
+  T* p = nullptr;
+  int64_t cap = 0;
+  int grow(int64_t need, int64_t keep, hipStream_t s) {
+    if (need <= cap) return 0;
+    int64_t ncap = cap ? cap : 1;
+    while (ncap < need) ncap *= 2;
+    T* np = nullptr;
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&np), sizeof(T) * static_cast<size_t>(ncap)));
+    if (p && keep > 0)
+      VR_HIP(hipMemcpyAsync(np, p, sizeof(T) * static_cast<size_t>(keep), hipMemcpyDeviceToDevice, s));
+    if (p) {
+      VR_HIP(hipStreamSynchronize(s));
+      VR_HIP(hipFree(p));
+    }
+    p = np;
+    cap = ncap;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// One SELL-64 slice of the sparse index: 64 consecutive rows, entries stored in chunks of 4
+// per lane so a wave reads 1 KiB per instruction: entry (lane, j) lives at
+// off + (j/4)*256 + lane*4 + (j%4). width is a multiple of 4; padding ids are -1.
+struct SliceDesc {
+  int64_t off;
+  int32_t row_base;
+  int32_t nrows;
+  int32_t width;
+  int32_t pad;
+};
+
+constexpr int kTileRows = 16;      // corpus rows per MFMA tile (v_mfma_f32_16x16x4_f32 M)
+constexpr int kTileK = 16;         // k elements per 1-KiB tile block
+constexpr int kTopkSeg = 4096;     // keys per block in the first select level
+constexpr int kMaxK = 256;         // largest top-k a search may ask for
+constexpr int kQueryBlock = 16;    // queries per dense pass (MFMA N)
+
+}  // namespace vr
+
+struct vr_engine {
+  int device = 0;
+  int dim = 0;
+  int kblocks = 0;  // dim / 16
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+
+  int64_t n_rows = 0;
+  int64_t n_live = 0;
+  int64_t cap_rows = 0;  // multiple of 64
+
+  // dense corpus, MFMA-tiled: [row/16][k/16][lane = (k%4)*16 + row%16][c = (k%16)/4]
+  vr::DevArray<float> corpus;
+  vr::DevArray<uint8_t> live;
+  vr::DevArray<int32_t> folder;
+  vr::DevArray<int32_t> index_folder;
+  vr::DevArray<int64_t> created;
+  vr::DevArray<int64_t> modified;
+  vr::DevArray<int32_t> row_slice;  // slice index of the row's sparse vector, -1 = none
+  int32_t max_folder_id = -1;
+  int32_t max_index_folder_id = -1;
+
+  // sparse index (SELL-64, see SliceDesc)
+  std::vector<vr::SliceDesc> slices_host;
+  vr::DevArray<vr::SliceDesc> slices;
+  int64_t n_slices_dev = 0;
+  vr::DevArray<int32_t> sp_idx;
+  vr::DevArray<float> sp_val;
+  int64_t sp_used = 0;
+  int64_t n_sparse_points = 0;
+
+  // document-frequency table: open addressing, key -1 = empty
+  vr::DevArray<int32_t> df_keys;
+  vr::DevArray<int32_t> df_cnt;
+  int64_t df_cap = 0;          // power of two
+  int64_t df_bound = 0;        // upper bound of distinct keys (exact count + nnz since last read)
+  int32_t* df_distinct = nullptr;  // device counter
+
+  // scratch
+  vr::DevArray<float> stage_dense;    // host->device staging of upsert / query rows
+  vr::DevArray<float> stage_len;      // per-row length
+  vr::DevArray<int64_t> stage_off;
+  vr::DevArray<int32_t> stage_idx;
+  vr::DevArray<float> stage_val;
+  vr::DevArray<int32_t> stage_i32a;
+  vr::DevArray<int32_t> stage_i32b;
+  vr::DevArray<int64_t> stage_i64a;
+  vr::DevArray<int64_t> stage_i64b;
+  vr::DevArray<float> q_tiled;        // 16-query image, kblocks KiB
+  vr::DevArray<float> scores;         // [16][cap_rows]
+  vr::DevArray<float> sp_scores;      // [cap_rows]
+  vr::DevArray<uint8_t> mask;         // [cap_rows]
+  vr::DevArray<uint8_t> pass_folder;  // per folder id
+  vr::DevArray<uint8_t> pass_ifolder;
+  vr::DevArray<uint64_t> cand_a;
+  vr::DevArray<uint64_t> cand_b;
+  vr::DevArray<int32_t> q_ids;
+  vr::DevArray<float> q_w;
+  void* pinned = nullptr;  // host pinned scratch for small D2H results
+  size_t pinned_bytes = 0;
+};
+
+namespace vr {
+
+// ---- dense.hip
+int dense_store_rows(vr_engine* e, const float* x_dev, int64_t n, int64_t first_row);
+int dense_make_query_image(vr_engine* e, const float* q_dev, int nq);
+int dense_scores(vr_engine* e, int nq, const uint8_t* mask_dev);
+int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out_dev);
+
+// ---- topk.hip
+// scores: [nq][stride] f32 with -inf / masked rows excluded; result keys (descending) for each
+// query are left in *out_keys (device, [nq][k]).
+int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, int nq, int k,
+                const uint64_t** out_keys);
+
+// ---- sparse.hip
+int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int64_t* off_host,
+                  const int64_t* off_dev, const int32_t* idx_dev, const float* val_dev);
+int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
+                  const uint8_t* mask_dev);
+int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
+                       int64_t* n_sparse_deleted);
+int sparse_lookup_df(vr_engine* e, const int32_t* ids_host, int n, int32_t* out_df_host);
+
+// ---- filter.hip
+// returns the device mask to use for this query (live[] when no filter is active)
+int filter_build_mask(vr_engine* e, const vr_filter* f, const uint8_t** mask_out);
+
+// ---- fusion.cpp (host only)
+int fuse_minmax(const int64_t* d_rows, const float* d_scores, int nd, const int64_t* s_rows,
+                const float* s_scores, int ns, int limit, double sparse_weight, int json_scores,
+                int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
+int fuse_rrf(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, int limit,
+             double sparse_weight, int64_t* out_rows, double* out_scores, int32_t* out_from_dense,
+             int32_t* out_count);
+
+inline uint32_t f32_order_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+}  // namespace vr

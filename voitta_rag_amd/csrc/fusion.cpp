@@ -1,0 +1,149 @@
+// Hybrid fusion on the host — the only arithmetic of the hot path that lives in the reference
+// itself. Restates VectorStoreService._hybrid_search, src/voitta/services/vector_store.py:659-697:
+//   normalize():  (s - min) / (max - min), or 1.0 for every item when max - min <= 0 (:659-669)
+//   union of ids (:675); missing side contributes 0.0 (:678-679)
+//   final = (1 - sparse_weight) * d + sparse_weight * s in Python floats = f64 (:634,:680)
+//   result object taken from the dense list when present (:682-685)
+//   sort by final descending, keep `limit`, overwrite score (:689-695)
+// The reference iterates a Python set, so ties in `final` come out in arbitrary order
+// (SURVEY.md F8); here ties go to the lower row id.
+//
+// json_scores: the reference receives scores over REST as JSON; the server prints an f32 with
+// the shortest decimal that round-trips and Python parses that decimal to the nearest f64
+// [EXT]. With json_scores != 0 the same transport is applied before the arithmetic.
+//
+// <= 6*limit candidates: latency, not roofline, matters; no GPU involved.
+
+#include <algorithm>
+#include <charconv>
+#include <cstdlib>
+#include <unordered_map>
+#include <vector>
+
+#include "engine_internal.h"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace vr {
+
+static double to_python_float(float s, int json_scores) {
+  if (!json_scores) return static_cast<double>(s);
+  char buf[64];
+  auto r = std::to_chars(buf, buf + sizeof(buf) - 1, s);
+  *r.ptr = '\0';
+  return std::strtod(buf, nullptr);
+}
+
+namespace {
+struct Cand {
+  int64_t row;
+  double d = 0.0, s = 0.0;
+  bool in_dense = false, in_sparse = false;
+  double final_score = 0.0;
+};
+
+void normalize(const float* scores, int n, int json_scores, std::vector<double>* out) {
+  out->assign(static_cast<size_t>(n), 0.0);
+  if (n == 0) return;
+  std::vector<double> v(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) v[static_cast<size_t>(i)] = to_python_float(scores[i], json_scores);
+  double mn = v[0], mx = v[0];
+  for (double x : v) {
+    mn = std::min(mn, x);
+    mx = std::max(mx, x);
+  }
+  double spread = mx - mn;
+  for (int i = 0; i < n; ++i)
+    (*out)[static_cast<size_t>(i)] = spread > 0 ? (v[static_cast<size_t>(i)] - mn) / spread : 1.0;
+}
+
+int emit(std::vector<Cand>& all, int limit, int64_t* out_rows, double* out_scores,
+         int32_t* out_from_dense, int32_t* out_count) {
+  std::sort(all.begin(), all.end(), [](const Cand& a, const Cand& b) {
+    if (a.final_score != b.final_score) return a.final_score > b.final_score;
+    return a.row < b.row;
+  });
+  int n = static_cast<int>(std::min<size_t>(all.size(), static_cast<size_t>(std::max(limit, 0))));
+  for (int i = 0; i < n; ++i) {
+    out_rows[i] = all[static_cast<size_t>(i)].row;
+    out_scores[i] = all[static_cast<size_t>(i)].final_score;
+    if (out_from_dense) out_from_dense[i] = all[static_cast<size_t>(i)].in_dense ? 1 : 0;
+  }
+  *out_count = n;
+  return 0;
+}
+
+void gather(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, std::vector<Cand>* all,
+            std::vector<int>* d_pos, std::vector<int>* s_pos) {
+  std::unordered_map<int64_t, int> at;
+  d_pos->resize(static_cast<size_t>(nd));
+  s_pos->resize(static_cast<size_t>(ns));
+  auto slot = [&](int64_t row) {
+    auto it = at.find(row);
+    if (it != at.end()) return it->second;
+    int i = static_cast<int>(all->size());
+    at.emplace(row, i);
+    Cand c;
+    c.row = row;
+    all->push_back(c);
+    return i;
+  };
+  for (int i = 0; i < nd; ++i) (*d_pos)[static_cast<size_t>(i)] = slot(d_rows[i]);
+  for (int i = 0; i < ns; ++i) (*s_pos)[static_cast<size_t>(i)] = slot(s_rows[i]);
+}
+}  // namespace
+
+int fuse_minmax(const int64_t* d_rows, const float* d_scores, int nd, const int64_t* s_rows,
+                const float* s_scores, int ns, int limit, double sparse_weight, int json_scores,
+                int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count) {
+  const double dense_weight = 1.0 - sparse_weight;  // vector_store.py:634
+  std::vector<double> dn, sn;
+  normalize(d_scores, nd, json_scores, &dn);
+  normalize(s_scores, ns, json_scores, &sn);
+  std::vector<Cand> all;
+  std::vector<int> dp, sp;
+  gather(d_rows, nd, s_rows, ns, &all, &dp, &sp);
+  // a later duplicate of an id overwrites the earlier one, as the dict assignment at :668 does
+  for (int i = 0; i < nd; ++i) {
+    Cand& c = all[static_cast<size_t>(dp[static_cast<size_t>(i)])];
+    c.d = dn[static_cast<size_t>(i)];
+    c.in_dense = true;
+  }
+  for (int i = 0; i < ns; ++i) {
+    Cand& c = all[static_cast<size_t>(sp[static_cast<size_t>(i)])];
+    c.s = sn[static_cast<size_t>(i)];
+    c.in_sparse = true;
+  }
+  for (Cand& c : all) {
+    double d = c.in_dense ? c.d : 0.0;
+    double s = c.in_sparse ? c.s : 0.0;
+    double a = dense_weight * d;
+    double b = sparse_weight * s;
+    c.final_score = a + b;
+  }
+  return emit(all, limit, out_rows, out_scores, out_from_dense, out_count);
+}
+
+// Reciprocal-rank fusion as the Qdrant server implements it for prefetch+fusion queries
+// [EXT]: score = sum over lists of 1 / (position + 2), position counted from 0. No reference
+// code path uses it (vector_store.py:638-639 explains why); offered because north_star names it.
+int fuse_rrf(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, int limit,
+             double /*sparse_weight*/, int64_t* out_rows, double* out_scores,
+             int32_t* out_from_dense, int32_t* out_count) {
+  std::vector<Cand> all;
+  std::vector<int> dp, sp;
+  gather(d_rows, nd, s_rows, ns, &all, &dp, &sp);
+  for (int i = 0; i < nd; ++i) {
+    Cand& c = all[static_cast<size_t>(dp[static_cast<size_t>(i)])];
+    c.final_score += 1.0 / (static_cast<double>(i) + 2.0);
+    c.in_dense = true;
+  }
+  for (int i = 0; i < ns; ++i) {
+    Cand& c = all[static_cast<size_t>(sp[static_cast<size_t>(i)])];
+    c.final_score += 1.0 / (static_cast<double>(i) + 2.0);
+    c.in_sparse = true;
+  }
+  return emit(all, limit, out_rows, out_scores, out_from_dense, out_count);
+}
+
+}  // namespace vr

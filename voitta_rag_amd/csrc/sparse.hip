@@ -1,0 +1,387 @@
+// Sparse (BM25) side of the store. Replaces what the Qdrant server does for the "bm25" sparse
+// vector configured with Modifier.IDF (reference: src/voitta/services/vector_store.py:95-99) on
+//   upsert  (vector_store.py:291-298,313; scripts/build_sparse_vectors.py:176-207)
+//   query   (vector_store.py:647-656)
+//
+// HBM layout: SELL-64 — every upsert batch is cut into slices of 64 consecutive rows, one row
+// per wavefront lane. Inside a slice the (token id, tf weight) entries of a row are sorted by
+// token id and stored in chunks of four: entry j of lane l sits at off + (j/4)*256 + l*4 + j%4,
+// so a wave reads 1 KiB of ids per instruction and each lane walks its own row in ascending
+// token-id order — the summation order the oracle restates. Padding ids are -1.
+//
+// Scoring is a brute-force scan (HBM bound; algorithmic bytes = 4 B per stored id, values are
+// touched only on a hit): score(d) = sum over shared terms, ascending id, of (q_t*idf_t)*d_t with
+// every multiply and add rounded to f32 separately; idf_t = ln(1 + (N - df_t + 0.5)/(df_t + 0.5))
+// with the argument formed in f32 and ln taken in f64 then rounded (SURVEY.md a13 [EXT]).
+// Document frequencies live in an open-addressing hash table in HBM (integer atomics only, so
+// the table content does not depend on arrival order).
+
+#include "engine_internal.h"
+
+#include <algorithm>
+
+namespace vr {
+
+// ---- document-frequency table ---------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t df_hash(int32_t id) {
+  uint32_t h = static_cast<uint32_t>(id) * 0x9E3779B1u;
+  return h ^ (h >> 15);
+}
+
+__device__ __forceinline__ void df_add(int32_t* keys, int32_t* cnt, int64_t cap, int32_t id,
+                                       int32_t delta, int32_t* distinct) {
+  uint64_t h = df_hash(id) & (cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    int32_t cur = keys[h];
+    if (cur == id) break;
+    if (cur == -1) {
+      int32_t prev = atomicCAS(&keys[h], -1, id);
+      if (prev == -1) {
+        atomicAdd(distinct, 1);
+        break;
+      }
+      if (prev == id) break;
+    }
+    h = (h + 1) & (cap - 1);
+  }
+  atomicAdd(&cnt[h], delta);
+}
+
+__device__ __forceinline__ int32_t df_get(const int32_t* keys, const int32_t* cnt, int64_t cap,
+                                          int32_t id) {
+  uint64_t h = df_hash(id) & (cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    int32_t cur = keys[h];
+    if (cur == id) return cnt[h];
+    if (cur == -1) return 0;
+    h = (h + 1) & (cap - 1);
+  }
+  return 0;
+}
+
+__global__ void df_init_kernel(int32_t* keys, int32_t* cnt, int64_t cap) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    keys[i] = -1;
+    cnt[i] = 0;
+  }
+}
+
+__global__ void df_rehash_kernel(const int32_t* okeys, const int32_t* ocnt, int64_t ocap,
+                                 int32_t* keys, int32_t* cnt, int64_t cap, int32_t* distinct) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < ocap && okeys[i] != -1) df_add(keys, cnt, cap, okeys[i], ocnt[i], distinct);
+}
+
+__global__ void df_update_kernel(const int32_t* __restrict__ idx, int64_t nnz, int32_t* keys,
+                                 int32_t* cnt, int64_t cap, int32_t* distinct) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < nnz) df_add(keys, cnt, cap, idx[i], 1, distinct);
+}
+
+static int df_ensure(vr_engine* e, int64_t incoming) {
+  if (e->df_cap == 0) {
+    e->df_cap = 1 << 20;
+    VR_TRY(e->df_keys.grow(e->df_cap, 0, e->stream));
+    VR_TRY(e->df_cnt.grow(e->df_cap, 0, e->stream));
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&e->df_distinct), sizeof(int32_t)));
+    VR_HIP(hipMemsetAsync(e->df_distinct, 0, sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(df_init_kernel, dim3(static_cast<unsigned>((e->df_cap + 255) / 256)),
+                       dim3(256), 0, e->stream, e->df_keys.p, e->df_cnt.p, e->df_cap);
+    e->df_bound = 0;
+  }
+  if ((e->df_bound + incoming) * 2 > e->df_cap) {
+    // the bound counts every nnz since the last exact read; refresh it before growing
+    int32_t exact = 0;
+    VR_HIP(hipMemcpyAsync(&exact, e->df_distinct, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    e->df_bound = exact;
+    if ((e->df_bound + incoming) * 2 > e->df_cap) {
+      int64_t ncap = e->df_cap;
+      while ((e->df_bound + incoming) * 2 > ncap) ncap *= 2;
+      DevArray<int32_t> nk, nc;
+      VR_TRY(nk.grow(ncap, 0, e->stream));
+      VR_TRY(nc.grow(ncap, 0, e->stream));
+      hipLaunchKernelGGL(df_init_kernel, dim3(static_cast<unsigned>((ncap + 255) / 256)), dim3(256),
+                         0, e->stream, nk.p, nc.p, ncap);
+      VR_HIP(hipMemsetAsync(e->df_distinct, 0, sizeof(int32_t), e->stream));
+      hipLaunchKernelGGL(df_rehash_kernel, dim3(static_cast<unsigned>((e->df_cap + 255) / 256)),
+                         dim3(256), 0, e->stream, e->df_keys.p, e->df_cnt.p, e->df_cap, nk.p, nc.p,
+                         ncap, e->df_distinct);
+      VR_HIP(hipStreamSynchronize(e->stream));
+      e->df_keys.release();
+      e->df_cnt.release();
+      e->df_keys = nk;
+      e->df_cnt = nc;
+      e->df_cap = ncap;
+    }
+  }
+  e->df_bound += incoming;
+  return 0;
+}
+
+// ---- SELL-64 build ----------------------------------------------------------------------------
+
+// One wave per slice; lane l copies CSR row (first + l) into its SELL column, padding with -1.
+// Rows must already be sorted by token id (vr_upsert sorts host input; the device BM25 kernel
+// emits sorted rows).
+__global__ __launch_bounds__(64) void sell_build_kernel(const SliceDesc* __restrict__ slices,
+                                                        int64_t slice0, int64_t batch_first_row,
+                                                        const int64_t* __restrict__ off,
+                                                        const int32_t* __restrict__ idx,
+                                                        const float* __restrict__ val,
+                                                        int32_t* __restrict__ sidx,
+                                                        float* __restrict__ sval,
+                                                        int32_t* __restrict__ row_slice) {
+  const SliceDesc d = slices[slice0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  int64_t begin = 0, end = 0;
+  if (lane < d.nrows) {
+    int64_t local = d.row_base + lane - batch_first_row;
+    begin = off[local];
+    end = off[local + 1];
+    row_slice[d.row_base + lane] = static_cast<int32_t>(slice0 + blockIdx.x);
+  }
+  const int len = static_cast<int>(end - begin);
+  for (int j = 0; j < d.width; ++j) {
+    int64_t dst = d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3);
+    bool has = j < len;
+    sidx[dst] = has ? idx[begin + j] : -1;
+    sval[dst] = has ? val[begin + j] : 0.0f;
+  }
+}
+
+int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int64_t* off_host,
+                  const int64_t* off_dev, const int32_t* idx_dev, const float* val_dev) {
+  if (n <= 0) return 0;
+  const int64_t nnz = off_host[n] - off_host[0];
+  VR_CHECK(off_host[0] == 0, "sparse offsets must start at 0");
+  VR_TRY(df_ensure(e, nnz));
+
+  const int64_t slice0 = static_cast<int64_t>(e->slices_host.size());
+  int64_t used = e->sp_used;
+  for (int64_t r = 0; r < n; r += 64) {
+    SliceDesc d;
+    d.off = used;
+    d.row_base = static_cast<int32_t>(first_row + r);
+    d.nrows = static_cast<int32_t>(std::min<int64_t>(64, n - r));
+    int64_t w = 0;
+    for (int i = 0; i < d.nrows; ++i) w = std::max(w, off_host[r + i + 1] - off_host[r + i]);
+    d.width = static_cast<int32_t>((w + 3) / 4 * 4);
+    d.pad = 0;
+    used += static_cast<int64_t>(d.width) * 64;
+    e->slices_host.push_back(d);
+  }
+  const int64_t n_new = static_cast<int64_t>(e->slices_host.size()) - slice0;
+  VR_TRY(e->sp_idx.grow(used, e->sp_used, e->stream));
+  VR_TRY(e->sp_val.grow(used, e->sp_used, e->stream));
+  VR_TRY(e->slices.grow(static_cast<int64_t>(e->slices_host.size()), slice0, e->stream));
+  VR_HIP(hipMemcpyAsync(e->slices.p + slice0, e->slices_host.data() + slice0,
+                        sizeof(SliceDesc) * static_cast<size_t>(n_new), hipMemcpyHostToDevice,
+                        e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));  // slices_host may reallocate on the next append
+  hipLaunchKernelGGL(sell_build_kernel, dim3(static_cast<unsigned>(n_new)), dim3(64), 0, e->stream,
+                     e->slices.p, slice0, first_row, off_dev, idx_dev, val_dev, e->sp_idx.p,
+                     e->sp_val.p, e->row_slice.p);
+  if (nnz > 0)
+    hipLaunchKernelGGL(df_update_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256),
+                       0, e->stream, idx_dev, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
+                       e->df_distinct);
+  VR_HIP(hipGetLastError());
+  e->sp_used = used;
+  e->n_slices_dev = static_cast<int64_t>(e->slices_host.size());
+  e->n_sparse_points += n;
+  return 0;
+}
+
+// ---- query ------------------------------------------------------------------------------------
+
+constexpr int kQHash = 1024;  // LDS hash slots for the query terms
+constexpr int kMaxQueryTerms = 256;
+
+// q_w[t] = q_val[t] * idf(t)
+__global__ void query_weights_kernel(const int32_t* __restrict__ q_idx,
+                                     const float* __restrict__ q_val, int nnz,
+                                     const int32_t* __restrict__ keys,
+                                     const int32_t* __restrict__ cnt, int64_t cap, float n_points,
+                                     float* __restrict__ q_w) {
+  int t = threadIdx.x;
+  if (t >= nnz) return;
+  float df = static_cast<float>(cap ? df_get(keys, cnt, cap, q_idx[t]) : 0);
+  float num = __fadd_rn(__fadd_rn(n_points, -df), 0.5f);
+  float den = __fadd_rn(df, 0.5f);
+  float arg = __fadd_rn(1.0f, __fdiv_rn(num, den));
+  float idf = static_cast<float>(log(static_cast<double>(arg)));
+  q_w[t] = __fmul_rn(q_val[t], idf);
+}
+
+__global__ __launch_bounds__(256) void sparse_scores_kernel(
+    const SliceDesc* __restrict__ slices, int64_t n_slices, const int32_t* __restrict__ sidx,
+    const float* __restrict__ sval, const int32_t* __restrict__ q_idx,
+    const float* __restrict__ q_w, int nnz, const uint8_t* __restrict__ mask,
+    float* __restrict__ scores) {
+  __shared__ int32_t hk[kQHash];
+  __shared__ float hv[kQHash];
+  for (int i = threadIdx.x; i < kQHash; i += 256) hk[i] = -1;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // <= 256 terms; serial insert keeps the table deterministic
+    for (int t = 0; t < nnz; ++t) {
+      int32_t id = q_idx[t];
+      uint32_t h = df_hash(id) & (kQHash - 1);
+      while (hk[h] != -1 && hk[h] != id) h = (h + 1) & (kQHash - 1);
+      hk[h] = id;
+      hv[h] = q_w[t];
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); s < n_slices;
+       s += wave_stride) {
+    const SliceDesc d = slices[s];
+    float acc = 0.0f;
+    bool hit = false;
+    const int4* ip = reinterpret_cast<const int4*>(sidx + d.off) + lane;
+    for (int c = 0; c < d.width / 4; ++c) {
+      int4 ids = ip[c * 64];
+      int32_t id4[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int32_t id = id4[u];
+        if (id < 0) continue;
+        uint32_t h = df_hash(id) & (kQHash - 1);
+        int32_t cur = hk[h];
+        while (cur != -1 && cur != id) {
+          h = (h + 1) & (kQHash - 1);
+          cur = hk[h];
+        }
+        if (cur == id) {
+          float v = sval[d.off + static_cast<int64_t>(c) * 256 + lane * 4 + u];
+          acc = __fadd_rn(acc, __fmul_rn(hv[h], v));
+          hit = true;
+        }
+      }
+    }
+    if (lane < d.nrows) {
+      int64_t row = d.row_base + lane;
+      scores[row] = (hit && mask[row]) ? acc : -__builtin_inff();
+    }
+  }
+}
+
+int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
+                  const uint8_t* mask_dev) {
+  VR_CHECK(nnz >= 1 && nnz <= kMaxQueryTerms, "sparse query with %d terms (1..%d supported)", nnz,
+           kMaxQueryTerms);
+  VR_TRY(e->sp_scores.grow(e->cap_rows, 0, e->stream));
+  VR_TRY(e->q_ids.grow(kMaxQueryTerms, 0, e->stream));
+  VR_TRY(e->q_w.grow(2 * kMaxQueryTerms, 0, e->stream));
+  // ascending token id, duplicates merged by keeping the first (Qdrant sorts sparse vectors by
+  // index on ingestion [EXT]); the hash lookup itself is order independent.
+  std::vector<std::pair<int32_t, float>> q(static_cast<size_t>(nnz));
+  for (int i = 0; i < nnz; ++i) q[static_cast<size_t>(i)] = {q_idx_host[i], q_val_host[i]};
+  std::stable_sort(q.begin(), q.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  q.erase(std::unique(q.begin(), q.end(), [](const auto& a, const auto& b) { return a.first == b.first; }),
+          q.end());
+  nnz = static_cast<int>(q.size());
+  int32_t* hid = static_cast<int32_t*>(e->pinned);
+  float* hval = reinterpret_cast<float*>(hid + kMaxQueryTerms);
+  for (int i = 0; i < nnz; ++i) {
+    hid[i] = q[static_cast<size_t>(i)].first;
+    hval[i] = q[static_cast<size_t>(i)].second;
+  }
+  VR_HIP(hipMemcpyAsync(e->q_ids.p, hid, sizeof(int32_t) * static_cast<size_t>(nnz),
+                        hipMemcpyHostToDevice, e->stream));
+  VR_HIP(hipMemcpyAsync(e->q_w.p + kMaxQueryTerms, hval, sizeof(float) * static_cast<size_t>(nnz),
+                        hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(query_weights_kernel, dim3(1), dim3(kMaxQueryTerms), 0, e->stream, e->q_ids.p,
+                     e->q_w.p + kMaxQueryTerms, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
+                     static_cast<float>(e->n_sparse_points), e->q_w.p);
+  VR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->sp_scores.p), 0xFF800000u,
+                           static_cast<size_t>(e->cap_rows), e->stream));
+  if (e->n_slices_dev > 0) {
+    int64_t blocks = (e->n_slices_dev + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sparse_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, e->q_ids.p,
+                       e->q_w.p, nnz, mask_dev, e->sp_scores.p);
+  }
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- delete -----------------------------------------------------------------------------------
+
+// rows are unique (host de-duplicates). counters[0] += rows that were live, counters[1] += of
+// those, rows that carried a sparse vector.
+__global__ void delete_rows_kernel(const int64_t* __restrict__ rows, int64_t n, int64_t n_rows,
+                                   uint8_t* __restrict__ live, const int32_t* __restrict__ row_slice,
+                                   const SliceDesc* __restrict__ slices,
+                                   const int32_t* __restrict__ sidx, int32_t* keys, int32_t* cnt,
+                                   int64_t cap, int32_t* distinct, int32_t* counters) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t row = rows[i];
+  if (row < 0 || row >= n_rows || !live[row]) return;
+  live[row] = 0;
+  atomicAdd(&counters[0], 1);
+  int32_t s = row_slice[row];
+  if (s < 0) return;
+  atomicAdd(&counters[1], 1);
+  const SliceDesc d = slices[s];
+  int lane = static_cast<int>(row - d.row_base);
+  for (int j = 0; j < d.width; ++j) {
+    int32_t id = sidx[d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3)];
+    if (id >= 0) df_add(keys, cnt, cap, id, -1, distinct);
+  }
+}
+
+int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
+                       int64_t* n_sparse_deleted) {
+  *n_deleted = 0;
+  *n_sparse_deleted = 0;
+  if (n <= 0) return 0;
+  VR_TRY(df_ensure(e, 0));
+  VR_TRY(e->stage_i32a.grow(2, 0, e->stream));
+  VR_HIP(hipMemsetAsync(e->stage_i32a.p, 0, 2 * sizeof(int32_t), e->stream));
+  hipLaunchKernelGGL(delete_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     e->stream, rows_dev, n, e->n_rows, e->live.p, e->row_slice.p, e->slices.p,
+                     e->sp_idx.p, e->df_keys.p, e->df_cnt.p, e->df_cap, e->df_distinct,
+                     e->stage_i32a.p);
+  VR_HIP(hipGetLastError());
+  int32_t c[2] = {0, 0};
+  VR_HIP(hipMemcpyAsync(c, e->stage_i32a.p, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  *n_deleted = c[0];
+  *n_sparse_deleted = c[1];
+  return 0;
+}
+
+// ---- statistics -------------------------------------------------------------------------------
+
+__global__ void df_lookup_kernel(const int32_t* __restrict__ ids, int n,
+                                 const int32_t* __restrict__ keys, const int32_t* __restrict__ cnt,
+                                 int64_t cap, int32_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = cap ? df_get(keys, cnt, cap, ids[i]) : 0;
+}
+
+int sparse_lookup_df(vr_engine* e, const int32_t* ids_host, int n, int32_t* out_df_host) {
+  if (n <= 0) return 0;
+  VR_TRY(e->stage_i32a.grow(n, 0, e->stream));
+  VR_TRY(e->stage_i32b.grow(n, 0, e->stream));
+  VR_HIP(hipMemcpyAsync(e->stage_i32a.p, ids_host, sizeof(int32_t) * static_cast<size_t>(n),
+                        hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(df_lookup_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     e->stream, e->stage_i32a.p, n, e->df_keys.p, e->df_cnt.p, e->df_cap,
+                     e->stage_i32b.p);
+  VR_HIP(hipGetLastError());
+  VR_HIP(hipMemcpyAsync(out_df_host, e->stage_i32b.p, sizeof(int32_t) * static_cast<size_t>(n),
+                        hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+}  // namespace vr

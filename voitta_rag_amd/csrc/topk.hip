@@ -1,0 +1,132 @@
+// Exact, deterministic top-k over a score column — the selection half of what the Qdrant server
+// does for client.query_points(limit=...) (reference: src/voitta/services/vector_store.py:612-617,
+// 640-656). Scores become 64-bit keys (order-preserving f32 bits << 32 | ~row) so that "larger
+// key" means "higher score, then lower row id" (tie rule: SURVEY.md F8) and keys are unique.
+// -inf marks excluded rows (masked, tombstoned, or no shared sparse term) and maps to key 0.
+//
+// Selection is k rounds of block-wide extract-max over keys held in registers: level 1 turns
+// each 4096-score segment into its k best keys, later levels fold up to 16384 keys per block
+// until one block is left. Integer work only; HBM traffic is N*4 bytes per query, which for
+// the corpus sizes of BASELINE.json (<= 4 MB per query) is served from L2 / Infinity Cache.
+
+#include "engine_internal.h"
+
+namespace vr {
+
+__device__ __forceinline__ uint64_t make_key(float s, int64_t row) {
+  if (s == -__builtin_inff()) return 0ull;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return (static_cast<uint64_t>(u) << 32) | static_cast<uint32_t>(0xFFFFFFFFu - static_cast<uint32_t>(row));
+}
+
+template <int THREADS, int ITEMS>
+__device__ __forceinline__ void block_extract_topk(uint64_t (&keys)[ITEMS], int k,
+                                                   uint64_t* __restrict__ out) {
+  constexpr int WAVES = THREADS / 64;
+  __shared__ uint64_t wmax[2][WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  uint64_t lmax = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) lmax = keys[i] > lmax ? keys[i] : lmax;
+
+  for (int r = 0; r < k; ++r) {
+    uint64_t m = lmax;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      uint64_t o = __shfl_xor(m, off);
+      m = o > m ? o : m;
+    }
+    if (lane == 0) wmax[r & 1][wave] = m;
+    __syncthreads();
+    uint64_t best = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      uint64_t v = wmax[r & 1][w];
+      best = v > best ? v : best;
+    }
+    if (threadIdx.x == 0) out[r] = best;
+    if (best == 0) {  // block-uniform: nothing left
+      for (int j = r + 1 + threadIdx.x; j < k; j += THREADS) out[j] = 0;
+      break;
+    }
+    if (lmax == best) {  // keys are unique: exactly one owner
+      lmax = 0;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        if (keys[i] == best) keys[i] = 0;
+        lmax = keys[i] > lmax ? keys[i] : lmax;
+      }
+    }
+  }
+}
+
+// level 1: scores [nq][stride] -> keys [nq][nseg][k]
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void select_from_scores_kernel(
+    const float* __restrict__ scores, int64_t stride, int64_t n, int k, uint64_t* __restrict__ out) {
+  const int64_t seg = blockIdx.x;
+  const int q = blockIdx.y;
+  const int64_t base = seg * (THREADS * ITEMS);
+  const float* s = scores + q * stride;
+  uint64_t keys[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    int64_t row = base + i * THREADS + threadIdx.x;
+    keys[i] = row < n ? make_key(s[row], row) : 0ull;
+  }
+  block_extract_topk<THREADS, ITEMS>(keys, k, out + (static_cast<int64_t>(q) * gridDim.x + seg) * k);
+}
+
+// level >= 2: keys [nq][count] -> keys [nq][nseg][k]
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void select_from_keys_kernel(const uint64_t* __restrict__ in,
+                                                                   int64_t count, int k,
+                                                                   uint64_t* __restrict__ out) {
+  const int64_t seg = blockIdx.x;
+  const int q = blockIdx.y;
+  const int64_t base = seg * (THREADS * ITEMS);
+  const uint64_t* s = in + q * count;
+  uint64_t keys[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    int64_t j = base + i * THREADS + threadIdx.x;
+    keys[i] = j < count ? s[j] : 0ull;
+  }
+  block_extract_topk<THREADS, ITEMS>(keys, k, out + (static_cast<int64_t>(q) * gridDim.x + seg) * k);
+}
+
+int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, int nq, int k,
+                const uint64_t** out_keys) {
+  VR_CHECK(k >= 1 && k <= kMaxK, "top-k of %d not in 1..%d", k, kMaxK);
+  VR_CHECK(nq >= 1, "no queries");
+  constexpr int T1 = 256, I1 = kTopkSeg / T1;
+  constexpr int T2 = 1024, I2 = 16;
+  int64_t nseg = (n + kTopkSeg - 1) / kTopkSeg;
+  if (nseg < 1) nseg = 1;
+  int64_t need = static_cast<int64_t>(nq) * nseg * k;
+  VR_TRY(e->cand_a.grow(need, 0, e->stream));
+  VR_TRY(e->cand_b.grow(need, 0, e->stream));
+  hipLaunchKernelGGL((select_from_scores_kernel<T1, I1>), dim3(static_cast<unsigned>(nseg), nq),
+                     dim3(T1), 0, e->stream, scores, stride, n, k, e->cand_a.p);
+  uint64_t* cur = e->cand_a.p;
+  uint64_t* nxt = e->cand_b.p;
+  int64_t count = nseg * k;
+  while (nseg > 1) {
+    int64_t nseg2 = (count + T2 * I2 - 1) / (T2 * I2);
+    hipLaunchKernelGGL((select_from_keys_kernel<T2, I2>), dim3(static_cast<unsigned>(nseg2), nq),
+                       dim3(T2), 0, e->stream, cur, count, k, nxt);
+    uint64_t* t = cur;
+    cur = nxt;
+    nxt = t;
+    nseg = nseg2;
+    count = nseg * k;
+  }
+  VR_HIP(hipGetLastError());
+  *out_keys = cur;
+  return 0;
+}
+
+}  // namespace vr

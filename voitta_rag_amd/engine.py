@@ -1,0 +1,260 @@
+"""Thin, typed Python face of the C-ABI (include/voitta_engine.h). NumPy arrays are passed as
+host pointers; anything exposing ``data_ptr()`` on the engine's device (a torch-ROCm tensor) is
+passed as a device pointer. No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import VR_FUSION_MINMAX, VR_FUSION_RRF, VR_MEM_DEVICE, VR_MEM_HOST, VR_TS_ABSENT, check
+
+__all__ = ["Engine", "SearchFilter", "VR_FUSION_MINMAX", "VR_FUSION_RRF", "VR_TS_ABSENT"]
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+@dataclass
+class SearchFilter:
+    """Integer form of VectorStoreService._build_filter's arguments
+    (reference: src/voitta/services/vector_store.py:462-530); ids are dictionary ids of
+    folder_path / index_folder strings. ``None`` for a must-set means "no such condition"."""
+
+    folder_filter: int | None = None
+    include_folders: list[int] | None = None
+    exclude_folders: list[int] = field(default_factory=list)
+    exclude_index_folders: list[int] = field(default_factory=list)
+    date_start: int | None = None
+    date_end: int | None = None
+    date_field: str | None = None  # "created" | "modified" | None
+
+    def is_empty(self) -> bool:
+        return (self.folder_filter is None and self.include_folders is None and not self.exclude_folders
+                and not self.exclude_index_folders and self.date_start is None and self.date_end is None)
+
+    def to_c(self):
+        """-> (VrFilter, keepalive) ; keepalive holds the arrays the struct points into."""
+        sets = []
+        if self.folder_filter is not None:
+            sets.append([int(self.folder_filter)])
+        if self.include_folders is not None:
+            sets.append([int(v) for v in self.include_folders])
+        ids = _np([v for s in sets for v in s], np.int32)
+        off = _np(np.cumsum([0] + [len(s) for s in sets]), np.int32)
+        nf = _np(self.exclude_folders, np.int32)
+        nif = _np(self.exclude_index_folders, np.int32)
+        f = _lib.VrFilter()
+        f.struct_size = C.sizeof(_lib.VrFilter)
+        f.n_must_folder_sets = len(sets)
+        f.must_folder_ids = _ptr(ids, C.c_int32)
+        f.must_folder_off = _ptr(off, C.c_int32)
+        f.not_folder_ids = _ptr(nf, C.c_int32)
+        f.n_not_folder = len(nf)
+        f.n_not_index_folder = len(nif)
+        f.not_index_folder_ids = _ptr(nif, C.c_int32)
+        f.has_date_start = int(self.date_start is not None)
+        f.has_date_end = int(self.date_end is not None)
+        f.date_start = int(self.date_start or 0)
+        f.date_end = int(self.date_end or 0)
+        # field_map.get(date_field, "source_modified_at"), vector_store.py:511-512
+        f.date_field = 1 if self.date_field == "created" else 0
+        return f, (ids, off, nf, nif)
+
+
+class Engine:
+    """One HBM-resident index on one GPU."""
+
+    def __init__(self, dim: int, device: int = 0, initial_rows: int = 0):
+        self._lib = _lib.load_library()
+        cfg = _lib.VrConfig()
+        cfg.struct_size = C.sizeof(_lib.VrConfig)
+        cfg.device = device
+        cfg.dim = dim
+        cfg.initial_rows = initial_rows
+        h = C.c_void_p()
+        check(self._lib.vr_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.dim = dim
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vr_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self) -> None:
+        check(self._lib.vr_sync(self._h))
+
+    def stream_ptr(self) -> int:
+        return int(self._lib.vr_stream(self._h) or 0)
+
+    # ---- store ----------------------------------------------------------------------------
+    def upsert(self, dense, sparse=None, folder_ids=None, index_folder_ids=None, created=None,
+               modified=None) -> int:
+        """dense: (n, D) f32 NumPy array or device tensor. sparse: None, or a list of
+        (indices, values) per row (host), or a CSR triple (off, idx, val) of NumPy arrays /
+        device tensors matching ``dense``'s memory space. Returns the first assigned row."""
+        if _is_device_tensor(dense):
+            mem = VR_MEM_DEVICE
+            n = int(dense.shape[0])
+            assert dense.is_contiguous() and tuple(dense.shape)[1] == self.dim
+            dptr = C.c_void_p(dense.data_ptr())
+            keep = [dense]
+        else:
+            mem = VR_MEM_HOST
+            d = _np(dense, np.float32).reshape(-1, self.dim)
+            n = d.shape[0]
+            dptr = C.c_void_p(d.ctypes.data)
+            keep = [d]
+        op = ip = vp = C.c_void_p(None)
+        if sparse is not None:
+            if isinstance(sparse, tuple) and len(sparse) == 3 and not isinstance(sparse[0], (list, tuple)):
+                off, idx, val = sparse
+            else:
+                off = np.zeros(n + 1, np.int64)
+                for i, (ix, _) in enumerate(sparse):
+                    off[i + 1] = off[i] + len(ix)
+                idx = np.concatenate([_np(ix, np.int32) for ix, _ in sparse]) if n else np.zeros(0, np.int32)
+                val = np.concatenate([_np(vs, np.float32) for _, vs in sparse]) if n else np.zeros(0, np.float32)
+            if mem == VR_MEM_DEVICE:
+                op, ip, vp = (C.c_void_p(t.data_ptr()) for t in (off, idx, val))
+                keep += [off, idx, val]
+            else:
+                off, idx, val = _np(off, np.int64), _np(idx, np.int32), _np(val, np.float32)
+                assert off.shape[0] == n + 1
+                op, ip, vp = (C.c_void_p(a.ctypes.data) for a in (off, idx, val))
+                keep += [off, idx, val]
+
+        def col(a, dtype, ctype):
+            if a is None:
+                return None
+            a = _np(a, dtype)
+            assert a.shape == (n,)
+            keep.append(a)
+            return _ptr(a, ctype)
+
+        first = C.c_int64(-1)
+        check(self._lib.vr_upsert(self._h, n, mem, dptr, op, ip, vp,
+                                  col(folder_ids, np.int32, C.c_int32),
+                                  col(index_folder_ids, np.int32, C.c_int32),
+                                  col(created, np.int64, C.c_int64), col(modified, np.int64, C.c_int64),
+                                  C.byref(first)))
+        return int(first.value)
+
+    def delete_rows(self, rows) -> None:
+        r = _np(rows, np.int64)
+        check(self._lib.vr_delete_rows(self._h, _ptr(r, C.c_int64), r.shape[0]))
+
+    def count(self) -> tuple[int, int]:
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.vr_count(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def get_dense(self, rows) -> np.ndarray:
+        r = _np(rows, np.int64)
+        out = np.empty((r.shape[0], self.dim), np.float32)
+        check(self._lib.vr_get_dense(self._h, _ptr(r, C.c_int64), r.shape[0], _ptr(out, C.c_float)))
+        return out
+
+    def sparse_stats(self, ids) -> tuple[np.ndarray, int]:
+        i = _np(ids, np.int32)
+        df = np.zeros(i.shape[0], np.int32)
+        n = C.c_int64()
+        check(self._lib.vr_sparse_stats(self._h, _ptr(i, C.c_int32), i.shape[0], _ptr(df, C.c_int32), C.byref(n)))
+        return df, int(n.value)
+
+    # ---- search ---------------------------------------------------------------------------
+    @staticmethod
+    def _filter(flt: SearchFilter | None):
+        if flt is None or flt.is_empty():
+            return None, None
+        f, keep = flt.to_c()
+        return C.byref(f), (f, keep)
+
+    def search_dense(self, queries, k: int, flt: SearchFilter | None = None):
+        """-> list of (rows int64[c], scores f32[c]) per query."""
+        if _is_device_tensor(queries):
+            mem, nq = VR_MEM_DEVICE, int(queries.shape[0])
+            qp = C.c_void_p(queries.data_ptr())
+        else:
+            q = _np(queries, np.float32).reshape(-1, self.dim)
+            mem, nq = VR_MEM_HOST, q.shape[0]
+            qp = C.c_void_p(q.ctypes.data)
+        rows = np.empty((nq, k), np.int64)
+        scores = np.empty((nq, k), np.float32)
+        counts = np.zeros(nq, np.int32)
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_search_dense(self._h, qp, nq, mem, k, fp, _ptr(rows, C.c_int64),
+                                        _ptr(scores, C.c_float), _ptr(counts, C.c_int32)))
+        del keep
+        return [(rows[i, : counts[i]].copy(), scores[i, : counts[i]].copy()) for i in range(nq)]
+
+    def search_sparse(self, q_idx, q_val, k: int, flt: SearchFilter | None = None):
+        qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
+        rows = np.empty(k, np.int64)
+        scores = np.empty(k, np.float32)
+        c = C.c_int32()
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_search_sparse(self._h, _ptr(qi, C.c_int32), _ptr(qv, C.c_float), qi.shape[0], k, fp,
+                                         _ptr(rows, C.c_int64), _ptr(scores, C.c_float), C.byref(c)))
+        del keep
+        return rows[: c.value].copy(), scores[: c.value].copy()
+
+    def search_hybrid(self, query, q_idx, q_val, limit: int, sparse_weight: float = 0.1,
+                      fusion: int = VR_FUSION_MINMAX, flt: SearchFilter | None = None):
+        """-> (rows int64[c], fused scores f64[c], from_dense int32[c])"""
+        if _is_device_tensor(query):
+            mem, qp = VR_MEM_DEVICE, C.c_void_p(query.data_ptr())
+        else:
+            q = _np(query, np.float32).reshape(self.dim)
+            mem, qp = VR_MEM_HOST, C.c_void_p(q.ctypes.data)
+        qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
+        rows = np.empty(limit, np.int64)
+        scores = np.empty(limit, np.float64)
+        fd = np.empty(limit, np.int32)
+        c = C.c_int32()
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_search_hybrid(self._h, qp, mem, _ptr(qi, C.c_int32), _ptr(qv, C.c_float), qi.shape[0],
+                                         limit, float(sparse_weight), fusion, fp, _ptr(rows, C.c_int64),
+                                         _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
+        del keep
+        return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
+
+
+def fuse_minmax(d_rows, d_scores, s_rows, s_scores, limit: int, sparse_weight: float, json_scores: bool = True):
+    """Host-only: the arithmetic of _hybrid_search on two result lists (no GPU needed)."""
+    lib = _lib.load_library()
+    dr, ds = _np(d_rows, np.int64), _np(d_scores, np.float32)
+    sr, ss = _np(s_rows, np.int64), _np(s_scores, np.float32)
+    cap = max(limit, 1)
+    rows = np.empty(cap, np.int64)
+    scores = np.empty(cap, np.float64)
+    fd = np.empty(cap, np.int32)
+    c = C.c_int32()
+    check(lib.vr_fuse_minmax(_ptr(dr, C.c_int64), _ptr(ds, C.c_float), dr.shape[0], _ptr(sr, C.c_int64),
+                             _ptr(ss, C.c_float), sr.shape[0], limit, float(sparse_weight), int(json_scores),
+                             _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
+    return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
