@@ -212,7 +212,11 @@ __global__ void query_weights_kernel(const int32_t* __restrict__ q_idx,
   float num = __fadd_rn(__fadd_rn(n_points, -df), 0.5f);
   float den = __fadd_rn(df, 0.5f);
   float arg = __fadd_rn(1.0f, __fdiv_rn(num, den));
-  float idf = static_cast<float>(log(static_cast<double>(arg)));
+  // ln in f64, rounded once to f32. The empty asm hides that `a` is a widened float: otherwise
+  // LLVM shrinks (float)log((double)x) to logf(x), whose last bit differs from the host's.
+  double a = static_cast<double>(arg);
+  asm volatile("" : "+v"(a));
+  float idf = static_cast<float>(log(a));
   q_w[t] = __fmul_rn(q_val[t], idf);
 }
 
