@@ -88,6 +88,48 @@ void vr_engine_destroy(vr_engine* e);
 int  vr_sync(vr_engine* e);
 /* the engine's hipStream_t, as an opaque pointer (bench.py records HIP events on it) */
 void* vr_stream(vr_engine* e);
+/* queue all further work on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+ * so that VR_MEM_DEVICE buffers produced on that stream need no extra synchronisation.
+ * NULL rebinds the engine's own stream, which is a blocking stream (ordered against the legacy
+ * null stream). Device buffers handed to the engine must be ready on the bound stream. */
+int  vr_set_stream(vr_engine* e, void* stream);
+
+/* ---- dense encode: replaces SentenceTransformer(...).encode (embedding.py:40,53,68-73,85) ----- */
+#define VR_POOL_MEAN 0
+#define VR_POOL_CLS  1
+
+/* BERT-family encoder description; values come from the checkpoint's config.json /
+ * sentence-transformers modules.json (SURVEY.md §8 model table). */
+typedef struct vr_bert_desc {
+  int32_t struct_size;
+  int32_t layers;
+  int32_t hidden;        /* H: multiple of 128, <= 1024 */
+  int32_t heads;         /* H / heads must be 32 or 64 */
+  int32_t intermediate;  /* multiple of 128 */
+  int32_t vocab;
+  int32_t max_pos;       /* max_position_embeddings; also the longest accepted sequence */
+  int32_t type_vocab;
+  int32_t pooling;       /* VR_POOL_MEAN | VR_POOL_CLS (sentence-transformers Pooling module) */
+  int32_t normalize;     /* 1 = L2-normalise (sentence-transformers Normalize module) */
+  float   eps;           /* layer_norm_eps */
+  int32_t reserved0;
+} vr_bert_desc;
+
+/* tensors: 5 + 16*layers f32 arrays in `mem`, HF BertModel state-dict order and [out,in] layout:
+ *   word_embeddings, position_embeddings, token_type_embeddings, embeddings.LayerNorm.{weight,bias},
+ *   then per layer: query.{weight,bias}, key.{weight,bias}, value.{weight,bias},
+ *   attention.output.dense.{weight,bias}, attention.output.LayerNorm.{weight,bias},
+ *   intermediate.dense.{weight,bias}, output.dense.{weight,bias}, output.LayerNorm.{weight,bias}.
+ * The engine copies (and re-packs) them; the caller's tensors may be freed afterwards.
+ * Replaces EmbeddingService.model's lazy SentenceTransformer(...) load (embedding.py:23-42). */
+int vr_encoder_load(vr_engine* e, const vr_bert_desc* desc, const void* const* tensors,
+                    int32_t n_tensors, int mem);
+
+/* ids: concatenated WordPiece ids of n_seq sequences ([CLS] ... [SEP] already added, truncated
+ * to max_pos by the tokenizer); offsets: n_seq+1 int32, offsets[0] = 0. Both in `mem`.
+ * out: n_seq x H f32 sentence embeddings in `out_mem`. */
+int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t n_seq, int mem,
+              float* out, int out_mem);
 
 /* ---- index: replaces VectorStoreService.store_chunks' client.upsert (vector_store.py:291-313)
  * and the Qdrant-side cosine normalisation on insert (SURVEY.md a10 [EXT]). ------------------- */

@@ -1,0 +1,93 @@
+"""HIP encoder (through vr_encoder_load / vr_encode) against (a) the golden embeddings produced by
+transformers.BertModel + sentence-transformers pooling/normalise on torch-CPU f32 and (b) the
+NumPy f64 restatement. Tolerance: BASELINE.json north_star asks for embedding cosine within 1e-4
+of the reference CPU path; an all-f32 path should be ~1e-7, so the test pins 1e-5 and reports the
+worst case."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bert as obert
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "bert_*.npz")))
+COS_TOL = 1e-5  # |1 - cos(ours, reference)|; north_star allows 1e-4
+ABS_TOL = 2e-5  # per-component, unit-length embeddings
+
+
+def _case(path):
+    from test_oracle_bert_cpu import load_case
+
+    return load_case(path)
+
+
+def _encode(shape, pooling, w, seqs):
+    from voitta_rag_amd import Engine
+    from voitta_rag_amd import encoder as enc
+
+    e = Engine(shape.hidden)
+    desc = enc.BertDesc(shape.layers, shape.hidden, shape.heads, shape.intermediate, vocab=shape.vocab,
+                        max_pos=shape.max_pos, type_vocab=shape.type_vocab, pooling=pooling, normalize=True,
+                        eps=shape.eps)
+    enc.load_encoder(e, desc, w)
+    ids = np.concatenate(seqs).astype(np.int32)
+    off = np.zeros(len(seqs) + 1, np.int32)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    out = enc.encode(e, ids, off)
+    e.close()
+    return out
+
+
+def _check(got, want, what):
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
+    worst = float(np.max(np.abs(1.0 - cos)))
+    print(f"{what}: worst |1-cos| = {worst:.3e}, worst abs diff = {np.max(np.abs(got - want)):.3e}")
+    assert worst < COS_TOL
+    assert np.max(np.abs(got - want)) < ABS_TOL
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "tiny" not in p], ids=lambda p: os.path.basename(p))
+def test_encoder_matches_transformers_golden(gpu, path):
+    shape, pooling, seed, seqs, want = _case(path)
+    w = obert.random_weights(shape, seed)
+    got = _encode(shape, pooling, w, seqs)
+    _check(got, want, os.path.basename(path) + " vs transformers f32")
+    _check(got, obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64), "vs numpy f64")
+
+
+@pytest.mark.parametrize("name,layers,lens", [
+    ("all-MiniLM-L6-v2", 6, [1, 2, 17, 64, 65, 128, 129, 200, 256, 31, 90, 90, 127]),
+    ("bge-base-en-v1.5", 2, [512, 3, 130, 64, 333]),
+    ("bge-large-en-v1.5", 1, [77, 512, 128]),
+    ("e5-base-v2", 1, [100, 110, 120, 130]),
+])
+def test_encoder_full_width_shapes(gpu, name, layers, lens):
+    """Real model widths (layers reduced so the CPU oracle stays in seconds), ragged lengths that
+    cross the 64-key tile and 128-row GEMM tile edges."""
+    base, pooling = obert.SHAPES[name]
+    shape = obert.BertShape(layers, base.hidden, base.heads, base.intermediate, vocab=1000, max_pos=base.max_pos)
+    w = obert.random_weights(shape, 99)
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+    got = _encode(shape, pooling, w, seqs)
+    want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
+    _check(got, want, name)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+def test_encode_is_batch_invariant_and_chunked(gpu):
+    """> 32768 tokens forces several workspace chunks; every sequence must come out identical to
+    encoding it alone (packed layout: no cross-sequence leakage)."""
+    base, pooling = obert.SHAPES["all-MiniLM-L6-v2"]
+    shape = obert.BertShape(1, base.hidden, base.heads, base.intermediate, vocab=500, max_pos=256)
+    w = obert.random_weights(shape, 3)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(1, 257, size=400).tolist()
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+    assert sum(lens) > 32768
+    all_out = _encode(shape, pooling, w, seqs)
+    for i in (0, 57, 199, 399):
+        one = _encode(shape, pooling, w, [seqs[i]])
+        assert np.array_equal(one[0], all_out[i])

@@ -44,6 +44,25 @@ class VrFilter(C.Structure):
     ]
 
 
+class VrBertDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("layers", C.c_int32),
+        ("hidden", C.c_int32),
+        ("heads", C.c_int32),
+        ("intermediate", C.c_int32),
+        ("vocab", C.c_int32),
+        ("max_pos", C.c_int32),
+        ("type_vocab", C.c_int32),
+        ("pooling", C.c_int32),
+        ("normalize", C.c_int32),
+        ("eps", C.c_float),
+        ("reserved0", C.c_int32),
+    ]
+
+
+VR_POOL_MEAN = 0
+VR_POOL_CLS = 1
 VR_MEM_HOST = 0
 VR_MEM_DEVICE = 1
 VR_TS_ABSENT = -(2**63)
@@ -64,6 +83,9 @@ SIGNATURES = {
     "vr_engine_destroy": (None, [_vp]),
     "vr_sync": (C.c_int, [_vp]),
     "vr_stream": (_vp, [_vp]),
+    "vr_set_stream": (C.c_int, [_vp, _vp]),
+    "vr_encoder_load": (C.c_int, [_vp, C.POINTER(VrBertDesc), C.POINTER(_vp), C.c_int32, C.c_int]),
+    "vr_encode": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int, _vp, C.c_int]),
     "vr_upsert": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _i32p, _i32p, _i64p, _i64p, _i64p]),
     "vr_delete_rows": (C.c_int, [_vp, _i64p, C.c_int64]),
     "vr_count": (C.c_int, [_vp, _i64p, _i64p]),

@@ -130,14 +130,17 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
   e->device = cfg->device;
   e->dim = cfg->dim;
   e->kblocks = cfg->dim / kTileK;
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+  // a blocking stream: it orders itself against the legacy null stream, so device buffers
+  // produced by a framework on its default stream are safe to hand in without extra events
+  if (hipStreamCreateWithFlags(&e->own_stream, hipStreamDefault) != hipSuccess) {
     set_error("hipStreamCreate failed");
     delete e;
     return -1;
   }
+  e->stream = e->own_stream;
   if (hipHostMalloc(&e->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc failed");
-    (void)hipStreamDestroy(e->stream);
+    (void)hipStreamDestroy(e->own_stream);
     delete e;
     return -1;
   }
@@ -155,6 +158,7 @@ void vr_engine_destroy(vr_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  encoder_release(e);
   e->corpus.release();
   e->live.release();
   e->folder.release();
@@ -188,7 +192,7 @@ void vr_engine_destroy(vr_engine* e) {
   e->q_ids.release();
   e->q_w.release();
   if (e->pinned) (void)hipHostFree(e->pinned);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
 
@@ -199,6 +203,33 @@ int vr_sync(vr_engine* e) {
 }
 
 void* vr_stream(vr_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int vr_set_stream(vr_engine* e, void* stream) {
+  VR_TRY(check_engine(e));
+  std::lock_guard<std::mutex> lock(e->mu);
+  VR_HIP(hipStreamSynchronize(e->stream));
+  e->stream = stream ? static_cast<hipStream_t>(stream) : e->own_stream;
+  return 0;
+}
+
+int vr_encoder_load(vr_engine* e, const vr_bert_desc* desc, const void* const* tensors,
+                    int32_t n_tensors, int mem) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(desc && tensors, "null argument");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  return encoder_load(e, desc, tensors, n_tensors, mem);
+}
+
+int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t n_seq, int mem,
+              float* out, int out_mem) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n_seq >= 0 && (n_seq == 0 || (ids && offsets && out)), "bad arguments");
+  VR_CHECK((mem == VR_MEM_HOST || mem == VR_MEM_DEVICE) && (out_mem == VR_MEM_HOST || out_mem == VR_MEM_DEVICE),
+           "bad mem");
+  std::lock_guard<std::mutex> lock(e->mu);
+  return encoder_encode(e, ids, offsets, n_seq, mem, out, out_mem);
+}
 
 int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
               const int32_t* sp_idx, const float* sp_val, const int32_t* folder_id,

@@ -1,0 +1,651 @@
+// Dense encode on the GPU: the BERT-family forward that SentenceTransformer.encode runs for the
+// reference (call sites: src/voitta/services/embedding.py:40,53,68-73,85; SURVEY.md a4 [EXT]).
+//
+// Layout: sequences are PACKED — activations are [T, H] over the T real tokens of a batch, with
+// an offsets array (cu) marking sequence boundaries. No padding rows exist, so no FLOP or byte is
+// spent on them (sentence-transformers pads to the longest sequence of each 32-batch; padding
+// never changes a result because masked logits underflow to exactly 0).
+//
+// Kernels (all f32; the matrix products run on the f32-input MFMA, which is an exact f32 fma
+// chain, so the only differences from the torch-CPU reference are summation orders):
+//   embed_ln_kernel   word+position+type gather, LayerNorm           HBM bound, 2*H*4 B/token
+//   gemm_f32_kernel   C = A W^T + b (+GELU | +residual)              MFMA bound (v_mfma_f32_32x32x2_f32)
+//                     128x128x32 block tile, 4 waves of 64x64, register-staged double-buffered LDS
+//   attention_kernel  softmax(Q K^T / sqrt(d)) V per (sequence, head) MFMA (v_mfma_f32_16x16x4_f32),
+//                     online softmax, keys streamed through LDS 64 at a time
+//   layernorm_kernel  LayerNorm over H                               HBM bound
+//   pool_kernel       mean / CLS pooling + L2 normalise              HBM bound
+// Algorithmic FLOP per token = L * (24 H^2 + 4 S H), of which the GEMMs are
+// 24 H^2 L: the dominant kernel of the indexing path.
+
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace vr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct LayerWeights {
+  float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+};
+
+struct Encoder {
+  vr_bert_desc d{};
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *lng = nullptr, *lnb = nullptr;
+  std::vector<LayerWeights> layers;
+  std::vector<float*> owned;  // every device allocation, for release
+  // workspace for up to ws_tokens packed tokens
+  int64_t ws_tokens = 0;
+  float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+  DevArray<int32_t> ids, cu;
+  DevArray<float> out;
+};
+
+// ---- elementwise / normalisation ---------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int kMaxPairs = 8;  // H <= 1024: H/128 float2 per lane
+
+// LayerNorm of one row held as float2 pairs per lane (biased variance, eps inside the sqrt)
+__device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs, int H,
+                                              const float* __restrict__ g,
+                                              const float* __restrict__ b, float eps, int lane,
+                                              float* __restrict__ out) {
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxPairs; ++i)
+    if (i < pairs) s += v[i].x + v[i].y;
+  const float mean = wave_sum(s) / static_cast<float>(H);
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxPairs; ++i)
+    if (i < pairs) {
+      float dx = v[i].x - mean, dy = v[i].y - mean;
+      q += dx * dx + dy * dy;
+    }
+  const float var = wave_sum(q) / static_cast<float>(H);
+  const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < kMaxPairs; ++i)
+    if (i < pairs) {
+      int e = (i * 64 + lane) * 2;
+      float2 gg = *reinterpret_cast<const float2*>(g + e);
+      float2 bb = *reinterpret_cast<const float2*>(b + e);
+      float2 o;
+      o.x = (v[i].x - mean) * inv * gg.x + bb.x;
+      o.y = (v[i].y - mean) * inv * gg.y + bb.y;
+      *reinterpret_cast<float2*>(out + e) = o;
+    }
+}
+
+// one wave per token: x[t] = LayerNorm(word[id] + pos[p] + type[0])
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids,
+                                                       const int32_t* __restrict__ cu, int n_seq,
+                                                       int tok_base, int T, int H, int vocab,
+                                                       const float* __restrict__ word,
+                                                       const float* __restrict__ pos,
+                                                       const float* __restrict__ type,
+                                                       const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps,
+                                                       float* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  // position = index inside the sequence: binary search of the offsets
+  int lo = 0, hi = n_seq;
+  const int tg = t + tok_base;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu[mid] <= tg) lo = mid; else hi = mid;
+  }
+  const int p = tg - cu[lo];
+  int id = ids[tg];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int pairs = H / 128;
+  float2 v[kMaxPairs];
+#pragma unroll
+  for (int i = 0; i < kMaxPairs; ++i)
+    if (i < pairs) {
+      int e = (i * 64 + lane) * 2;
+      float2 w = *reinterpret_cast<const float2*>(word + static_cast<int64_t>(id) * H + e);
+      float2 pp = *reinterpret_cast<const float2*>(pos + static_cast<int64_t>(p) * H + e);
+      float2 tt = *reinterpret_cast<const float2*>(type + e);
+      v[i].x = w.x + pp.x + tt.x;
+      v[i].y = w.y + pp.y + tt.y;
+    }
+  row_layernorm(v, pairs, H, g, b, eps, lane, x + static_cast<int64_t>(t) * H);
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int T, int H,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b, float eps,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int pairs = H / 128;
+  float2 v[kMaxPairs];
+#pragma unroll
+  for (int i = 0; i < kMaxPairs; ++i)
+    if (i < pairs) v[i] = *reinterpret_cast<const float2*>(in + static_cast<int64_t>(t) * H + (i * 64 + lane) * 2);
+  row_layernorm(v, pairs, H, g, b, eps, lane, out + static_cast<int64_t>(t) * H);
+}
+
+// one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
+                                                   const int32_t* __restrict__ cu, int seq0,
+                                                   int tok_base, int H, int pooling, int normalize,
+                                                   float* __restrict__ out) {
+  __shared__ float red[4];
+  const int seq = seq0 + blockIdx.x;
+  const int t0 = cu[seq] - tok_base;
+  const int len = cu[seq + 1] - cu[seq];
+  float vals[4];
+  float ss = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int c = threadIdx.x + 256 * j;
+    float v = 0.0f;
+    if (c < H && len > 0) {
+      if (pooling == 1) {
+        v = x[static_cast<int64_t>(t0) * H + c];
+      } else {
+        float acc = 0.0f;
+        for (int t = 0; t < len; ++t) acc += x[static_cast<int64_t>(t0 + t) * H + c];
+        v = acc / fmaxf(static_cast<float>(len), 1e-9f);
+      }
+    }
+    vals[j] = v;
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  const float den = normalize ? fmaxf(norm, 1e-12f) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int c = threadIdx.x + 256 * j;
+    if (c < H) out[static_cast<int64_t>(seq) * H + c] = vals[j] / den;
+  }
+}
+
+// ---- GEMM: C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU | + R) ---------------------------------------
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BK + 4;  // padded LDS row (floats); rows stay 16-byte aligned
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A,
+                                                       const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ R,
+                                                       float* __restrict__ C, int M, int N, int K) {
+  __shared__ float lds[2 * (BM + BN) * LDT];
+  float* sA = lds;                 // [2][BM*LDT]
+  float* sB = lds + 2 * BM * LDT;  // [2][BN*LDT]
+
+  // XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk consecutive tiles of one
+  // row panel, so the A panel and the W columns they re-read stay in that XCD's L2.
+  const int tiles_n = N / BN;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+  const int bm = (swz / tiles_n) * BM;
+  const int bn = (swz % tiles_n) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // global -> register staging: thread covers rows (tid>>3) + 32p, 16 bytes at column (tid&7)*4
+  const int lrow = tid >> 3;
+  const int lcol = (tid & 7) * 4;
+  // A rows past M are clamped to row M-1: they only feed C rows that are never stored.
+  const float* w_g = W + static_cast<int64_t>(bn + lrow) * K + lcol;
+  const int64_t rstep = static_cast<int64_t>(32) * K;
+  const int last = M - 1;
+  const float* a_g0 = A + static_cast<int64_t>(min(bm + lrow, last)) * K + lcol;
+  const float* a_g1 = A + static_cast<int64_t>(min(bm + lrow + 32, last)) * K + lcol;
+  const float* a_g2 = A + static_cast<int64_t>(min(bm + lrow + 64, last)) * K + lcol;
+  const float* a_g3 = A + static_cast<int64_t>(min(bm + lrow + 96, last)) * K + lcol;
+  float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define VR_LOAD_TILE(k0)                                                                         \
+  do {                                                                                           \
+    ra0 = *reinterpret_cast<const float4*>(a_g0 + (k0));                                         \
+    ra1 = *reinterpret_cast<const float4*>(a_g1 + (k0));                                         \
+    ra2 = *reinterpret_cast<const float4*>(a_g2 + (k0));                                         \
+    ra3 = *reinterpret_cast<const float4*>(a_g3 + (k0));                                         \
+    rw0 = *reinterpret_cast<const float4*>(w_g + (k0));                                          \
+    rw1 = *reinterpret_cast<const float4*>(w_g + rstep + (k0));                                  \
+    rw2 = *reinterpret_cast<const float4*>(w_g + 2 * rstep + (k0));                              \
+    rw3 = *reinterpret_cast<const float4*>(w_g + 3 * rstep + (k0));                              \
+  } while (0)
+#define VR_STORE_TILE(buf)                                                                       \
+  do {                                                                                           \
+    float* da = sA + (buf) * BM * LDT + lrow * LDT + lcol;                                       \
+    float* db = sB + (buf) * BN * LDT + lrow * LDT + lcol;                                       \
+    *reinterpret_cast<float4*>(da) = ra0;                                                        \
+    *reinterpret_cast<float4*>(da + 32 * LDT) = ra1;                                             \
+    *reinterpret_cast<float4*>(da + 64 * LDT) = ra2;                                             \
+    *reinterpret_cast<float4*>(da + 96 * LDT) = ra3;                                             \
+    *reinterpret_cast<float4*>(db) = rw0;                                                        \
+    *reinterpret_cast<float4*>(db + 32 * LDT) = rw1;                                             \
+    *reinterpret_cast<float4*>(db + 64 * LDT) = rw2;                                             \
+    *reinterpret_cast<float4*>(db + 96 * LDT) = rw3;                                             \
+  } while (0)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk = K / BK;
+  VR_LOAD_TILE(0);
+  VR_STORE_TILE(0);
+  __syncthreads();
+
+  // MFMA operand addressing: lane l supplies row/col (l & 31) and k-slot (l >> 5); its float4
+  // read at k offset kk + 4*(l>>5) feeds four MFMAs (component c covers k = kk + 4*(l>>5) + c;
+  // A and B use the same map, so every product pairs equal k).
+  const int frow = lane & 31;
+  const int fk = 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) VR_LOAD_TILE((kt + 1) * BK);
+    const float* a_base = sA + buf * BM * LDT + (wm * 64 + frow) * LDT + fk;
+    const float* b_base = sB + buf * BN * LDT + (wn * 64 + frow) * LDT + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float4 a0 = *reinterpret_cast<const float4*>(a_base + kk);
+      float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * LDT + kk);
+      float4 b0 = *reinterpret_cast<const float4*>(b_base + kk);
+      float4 b1 = *reinterpret_cast<const float4*>(b_base + 32 * LDT + kk);
+      const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+      const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) VR_STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+
+#undef VR_LOAD_TILE
+#undef VR_STORE_TILE
+
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = bn + wn * 64 + j * 32 + (lane & 31);
+      const float bs = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][r] + bs;
+          if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+          if (EPI == EPI_BIAS_RESIDUAL) v += R[static_cast<int64_t>(row) * N + col];
+          C[static_cast<int64_t>(row) * N + col] = v;
+        }
+      }
+    }
+}
+
+static int launch_gemm(hipStream_t s, int epi, const float* A, const float* W, const float* bias,
+                       const float* R, float* C, int M, int N, int K) {
+  VR_CHECK(N % BN == 0 && K % BK == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, BN, BK);
+  if (M <= 0) return 0;
+  const int grid = ((M + BM - 1) / BM) * (N / BN);
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, A, W, bias, R, C, M, N, K);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, A, W, bias, R, C, M, N, K);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS_RESIDUAL>), dim3(grid), dim3(256), 0, s, A, W, bias, R, C, M, N, K);
+      break;
+  }
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- attention -----------------------------------------------------------------------------------
+
+// One block = 64 queries of one (sequence, head); wave w owns queries 16w..16w+15.
+// S^T = K Q^T is computed with keys on the MFMA rows, so a lane (q = lane & 15, g = lane >> 4)
+// ends up holding the logits of query q against keys 4g..4g+3 of each 16-key tile: exactly the B
+// operand layout of the following O^T += V^T P^T product — no transpose, no LDS round trip for P.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+                                                        const int32_t* __restrict__ cu, int seq0,
+                                                        int tok_base, int H, int qblocks, float scale,
+                                                        float* __restrict__ ctx) {
+  constexpr int LDK = DH + 4;
+  constexpr int NS = DH / 16;  // 16-wide d blocks
+  __shared__ float sK[64 * LDK];
+  __shared__ float sV[64 * LDK];
+  const int seq = seq0 + blockIdx.x / qblocks;
+  const int qb = blockIdx.x % qblocks;
+  const int head = blockIdx.y;
+  const int t0 = cu[seq] - tok_base;
+  const int len = cu[seq + 1] - cu[seq];
+  if (qb * 64 >= len) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int q_tok = qb * 64 + wave * 16 + qi;
+  const bool q_valid = q_tok < len;
+  const int64_t row3 = 3 * static_cast<int64_t>(H);
+
+  float4 qf[NS];
+  {
+    const float* qp = qkv + (t0 + (q_valid ? q_tok : len - 1)) * row3 + head * DH + 4 * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const float4*>(qp + 16 * s);
+  }
+  f32x4 o[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -__builtin_inff();
+  float l = 0.0f;
+
+  for (int kt = 0; kt < len; kt += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (DH / 4); idx += 256) {
+      const int key = idx / (DH / 4), c4 = idx % (DH / 4);
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (kt + key < len) {
+        const float* p = qkv + (t0 + kt + key) * row3 + H + head * DH + c4 * 4;
+        kv = *reinterpret_cast<const float4*>(p);
+        vv = *reinterpret_cast<const float4*>(p + H);
+      }
+      *reinterpret_cast<float4*>(sK + key * LDK + c4 * 4) = kv;
+      *reinterpret_cast<float4*>(sV + key * LDK + c4 * 4) = vv;
+    }
+    __syncthreads();
+
+    f32x4 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float4 kf = *reinterpret_cast<const float4*>(sK + (t * 16 + qi) * LDK + 16 * s + 4 * g);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[s].x, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[s].y, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[s].z, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[s].w, st[t], 0, 0, 0);
+      }
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt + t * 16 + 4 * g + r;
+        const float v = key < len ? st[t][r] * scale : -__builtin_inff();
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);  // finite: key kt < len is always valid
+    const float alpha = expf(m - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(st[t][r] - m_new);
+        st[t][r] = p;
+        psum += p;
+      }
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vrow = sV + (t * 16 + 4 * g + r) * LDK + qi;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          o[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * s], st[t][r], o[s], 0, 0, 0);
+      }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (q_valid) {
+    const float inv = 1.0f / l;
+    float* op = ctx + static_cast<int64_t>(t0 + q_tok) * H + head * DH + 4 * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float4 v = make_float4(o[s][0] * inv, o[s][1] * inv, o[s][2] * inv, o[s][3] * inv);
+      *reinterpret_cast<float4*>(op + 16 * s) = v;
+    }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_floats, int mem, float** out) {
+  float* p = nullptr;
+  VR_HIP(hipMalloc(reinterpret_cast<void**>(&p), n_floats * sizeof(float)));
+  enc->owned.push_back(p);
+  if (src)
+    VR_HIP(hipMemcpyAsync(p, src, n_floats * sizeof(float),
+                          mem == VR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e->stream));
+  *out = p;
+  return 0;
+}
+
+void encoder_release(vr_engine* e) {
+  Encoder* enc = static_cast<Encoder*>(e->encoder);
+  if (!enc) return;
+  for (float* p : enc->owned) (void)hipFree(p);
+  enc->ids.release();
+  enc->cu.release();
+  enc->out.release();
+  delete enc;
+  e->encoder = nullptr;
+}
+
+int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int n_tensors, int mem) {
+  VR_CHECK(d->struct_size == static_cast<int32_t>(sizeof(vr_bert_desc)), "vr_bert_desc size mismatch");
+  const int H = d->hidden, I = d->intermediate, L = d->layers;
+  VR_CHECK(L >= 1 && H >= 128 && H % 128 == 0 && H <= 1024, "hidden %d must be a multiple of 128 in 128..1024", H);
+  VR_CHECK(I % 128 == 0 && I % BK == 0, "intermediate %d must be a multiple of 128", I);
+  VR_CHECK(d->heads >= 1 && H % d->heads == 0 && (H / d->heads == 32 || H / d->heads == 64),
+           "head size %d unsupported (32 or 64)", d->heads ? H / d->heads : 0);
+  VR_CHECK(n_tensors == 5 + 16 * L, "expected %d tensors, got %d", 5 + 16 * L, n_tensors);
+  VR_CHECK(d->pooling == 0 || d->pooling == 1, "pooling must be 0 (mean) or 1 (cls)");
+  for (int i = 0; i < n_tensors; ++i) VR_CHECK(t[i] != nullptr, "tensor %d is null", i);
+  encoder_release(e);
+  Encoder* enc = new Encoder();
+  e->encoder = enc;
+  enc->d = *d;
+  const size_t HH = static_cast<size_t>(H) * H;
+  VR_TRY(dev_alloc_copy(e, enc, t[0], static_cast<size_t>(d->vocab) * H, mem, &enc->word));
+  VR_TRY(dev_alloc_copy(e, enc, t[1], static_cast<size_t>(d->max_pos) * H, mem, &enc->pos));
+  VR_TRY(dev_alloc_copy(e, enc, t[2], static_cast<size_t>(d->type_vocab) * H, mem, &enc->type));
+  VR_TRY(dev_alloc_copy(e, enc, t[3], H, mem, &enc->lng));
+  VR_TRY(dev_alloc_copy(e, enc, t[4], H, mem, &enc->lnb));
+  const hipMemcpyKind kind = mem == VR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  for (int l = 0; l < L; ++l) {
+    const void* const* w = t + 5 + 16 * l;  // q_w q_b k_w k_b v_w v_b o_w o_b ln1_g ln1_b i_w i_b f_w f_b ln2_g ln2_b
+    LayerWeights lw{};
+    VR_TRY(dev_alloc_copy(e, enc, nullptr, 3 * HH, mem, &lw.wqkv));
+    VR_TRY(dev_alloc_copy(e, enc, nullptr, 3 * static_cast<size_t>(H), mem, &lw.bqkv));
+    for (int p = 0; p < 3; ++p) {  // fused QKV projection: rows [0,H) = query, [H,2H) = key, [2H,3H) = value
+      VR_HIP(hipMemcpyAsync(lw.wqkv + p * HH, w[2 * p], HH * sizeof(float), kind, e->stream));
+      VR_HIP(hipMemcpyAsync(lw.bqkv + p * H, w[2 * p + 1], H * sizeof(float), kind, e->stream));
+    }
+    VR_TRY(dev_alloc_copy(e, enc, w[6], HH, mem, &lw.wo));
+    VR_TRY(dev_alloc_copy(e, enc, w[7], H, mem, &lw.bo));
+    VR_TRY(dev_alloc_copy(e, enc, w[8], H, mem, &lw.ln1g));
+    VR_TRY(dev_alloc_copy(e, enc, w[9], H, mem, &lw.ln1b));
+    VR_TRY(dev_alloc_copy(e, enc, w[10], static_cast<size_t>(I) * H, mem, &lw.w1));
+    VR_TRY(dev_alloc_copy(e, enc, w[11], I, mem, &lw.b1));
+    VR_TRY(dev_alloc_copy(e, enc, w[12], static_cast<size_t>(I) * H, mem, &lw.w2));
+    VR_TRY(dev_alloc_copy(e, enc, w[13], H, mem, &lw.b2));
+    VR_TRY(dev_alloc_copy(e, enc, w[14], H, mem, &lw.ln2g));
+    VR_TRY(dev_alloc_copy(e, enc, w[15], H, mem, &lw.ln2b));
+    enc->layers.push_back(lw);
+  }
+  VR_HIP(hipStreamSynchronize(e->stream));  // host sources may be freed by the caller now
+  return 0;
+}
+
+static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
+  if (tokens <= enc->ws_tokens) return 0;
+  VR_HIP(hipStreamSynchronize(e->stream));
+  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn}) {
+    if (*p) {
+      enc->owned.erase(std::remove(enc->owned.begin(), enc->owned.end(), *p), enc->owned.end());
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  }
+  const size_t H = static_cast<size_t>(enc->d.hidden), I = static_cast<size_t>(enc->d.intermediate);
+  const size_t T = static_cast<size_t>(tokens);
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->x));
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, T * 3 * H, 0, &enc->qkv));
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->ctx));
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->tmp));
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, T * I, 0, &enc->ffn));
+  enc->ws_tokens = tokens;
+  return 0;
+}
+
+// forward of sequences [seq0, seq1) whose tokens are ids_dev[tok_base .. tok_base + T)
+static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, const int32_t* cu_dev,
+                         int n_seq_total, int seq0, int seq1, int tok_base, int T, int max_len,
+                         float* out_dev) {
+  const vr_bert_desc& d = enc->d;
+  const int H = d.hidden, I = d.intermediate, nh = d.heads, dh = H / nh;
+  hipStream_t s = e->stream;
+  const unsigned row_blocks = static_cast<unsigned>((T + 3) / 4);
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
+                     tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
+                     enc->x);
+  const int qblocks = (max_len + 63) / 64;
+  const float scale = 1.0f / sqrtf(static_cast<float>(dh));
+  for (const LayerWeights& w : enc->layers) {
+    VR_TRY(launch_gemm(s, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
+    dim3 agrid(static_cast<unsigned>((seq1 - seq0) * qblocks), static_cast<unsigned>(nh));
+    if (dh == 64)
+      hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
+                         qblocks, scale, enc->ctx);
+    else
+      hipLaunchKernelGGL((attention_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
+                         qblocks, scale, enc->ctx);
+    VR_TRY(launch_gemm(s, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
+    hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln1g, w.ln1b,
+                       d.eps, enc->x);
+    VR_TRY(launch_gemm(s, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
+    VR_TRY(launch_gemm(s, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
+    hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln2g, w.ln2b,
+                       d.eps, enc->x);
+  }
+  hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(seq1 - seq0)), dim3(256), 0, s, enc->x, cu_dev,
+                     seq0, tok_base, H, d.pooling, d.normalize, out_dev);
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
+constexpr int64_t kMaxChunkTokens = 32768;
+
+int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int n_seq, int mem,
+                   float* out, int out_mem) {
+  Encoder* enc = static_cast<Encoder*>(e->encoder);
+  VR_CHECK(enc != nullptr, "no encoder loaded (vr_encoder_load)");
+  if (n_seq <= 0) return 0;
+  const int H = enc->d.hidden;
+  // offsets are needed on the host to cut chunks
+  std::vector<int32_t> cu_host(static_cast<size_t>(n_seq) + 1);
+  const int32_t* ids_dev = ids;
+  const int32_t* cu_dev = offsets;
+  if (mem == VR_MEM_HOST) {
+    memcpy(cu_host.data(), offsets, sizeof(int32_t) * cu_host.size());
+  } else {
+    VR_HIP(hipMemcpyAsync(cu_host.data(), offsets, sizeof(int32_t) * cu_host.size(), hipMemcpyDeviceToHost,
+                          e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+  }
+  VR_CHECK(cu_host[0] == 0, "offsets must start at 0");
+  const int64_t T_all = cu_host[static_cast<size_t>(n_seq)];
+  for (int i = 0; i < n_seq; ++i) {
+    int len = cu_host[static_cast<size_t>(i) + 1] - cu_host[static_cast<size_t>(i)];
+    VR_CHECK(len >= 1 && len <= enc->d.max_pos, "sequence %d has %d tokens (1..%d allowed)", i, len,
+             enc->d.max_pos);
+  }
+  if (mem == VR_MEM_HOST) {
+    VR_TRY(enc->ids.grow(T_all, 0, e->stream));
+    VR_TRY(enc->cu.grow(n_seq + 1, 0, e->stream));
+    VR_HIP(hipMemcpyAsync(enc->ids.p, ids, sizeof(int32_t) * static_cast<size_t>(T_all), hipMemcpyHostToDevice,
+                          e->stream));
+    VR_HIP(hipMemcpyAsync(enc->cu.p, offsets, sizeof(int32_t) * cu_host.size(), hipMemcpyHostToDevice,
+                          e->stream));
+    ids_dev = enc->ids.p;
+    cu_dev = enc->cu.p;
+  }
+  float* out_dev = out;
+  if (out_mem == VR_MEM_HOST) {
+    VR_TRY(enc->out.grow(static_cast<int64_t>(n_seq) * H, 0, e->stream));
+    out_dev = enc->out.p;
+  }
+  int seq0 = 0;
+  while (seq0 < n_seq) {
+    int seq1 = seq0;
+    int max_len = 0;
+    int64_t T = 0;
+    while (seq1 < n_seq) {
+      int len = cu_host[static_cast<size_t>(seq1) + 1] - cu_host[static_cast<size_t>(seq1)];
+      if (seq1 > seq0 && T + len > kMaxChunkTokens) break;
+      T += len;
+      max_len = std::max(max_len, len);
+      ++seq1;
+    }
+    VR_TRY(ensure_workspace(e, enc, std::max<int64_t>(T, 1024)));
+    VR_TRY(forward_chunk(e, enc, ids_dev, cu_dev, n_seq, seq0, seq1, cu_host[static_cast<size_t>(seq0)],
+                         static_cast<int>(T), max_len, out_dev));
+    seq0 = seq1;
+  }
+  if (out_mem == VR_MEM_HOST) {
+    VR_HIP(hipMemcpyAsync(out, out_dev, sizeof(float) * static_cast<size_t>(n_seq) * H, hipMemcpyDeviceToHost,
+                          e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+  } else if (mem == VR_MEM_HOST) {
+    VR_HIP(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+}  // namespace vr

@@ -93,7 +93,8 @@ struct vr_engine {
   int device = 0;
   int dim = 0;
   int kblocks = 0;  // dim / 16
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // stream every kernel of a call is queued on
+  hipStream_t own_stream = nullptr;  // created by the engine; `stream` points here unless rebound
   std::mutex mu;
 
   int64_t n_rows = 0;
@@ -149,6 +150,8 @@ struct vr_engine {
   vr::DevArray<float> q_w;
   void* pinned = nullptr;  // host pinned scratch for small D2H results
   size_t pinned_bytes = 0;
+
+  void* encoder = nullptr;  // vr::Encoder (encoder.hip)
 };
 
 namespace vr {
@@ -173,6 +176,12 @@ int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
 int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
                        int64_t* n_sparse_deleted);
 int sparse_lookup_df(vr_engine* e, const int32_t* ids_host, int n, int32_t* out_df_host);
+
+// ---- encoder.hip
+int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* tensors, int n_tensors, int mem);
+int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int n_seq, int mem,
+                   float* out, int out_mem);
+void encoder_release(vr_engine* e);
 
 // ---- filter.hip
 // returns the device mask to use for this query (live[] when no filter is active)

@@ -111,6 +111,19 @@ class Engine:
     def stream_ptr(self) -> int:
         return int(self._lib.vr_stream(self._h) or 0)
 
+    def set_stream(self, stream_ptr: int | None) -> None:
+        """Queue all further engine work on this hipStream_t (0/None = the engine's own stream)."""
+        check(self._lib.vr_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+        self._bound = int(stream_ptr or 0)
+
+    def _follow(self, tensor) -> None:
+        """Device tensors are produced on the framework's current stream: run there too."""
+        import torch
+
+        ptr = int(torch.cuda.current_stream(tensor.device).cuda_stream)
+        if ptr != getattr(self, "_bound", 0):
+            self.set_stream(ptr)
+
     # ---- store ----------------------------------------------------------------------------
     def upsert(self, dense, sparse=None, folder_ids=None, index_folder_ids=None, created=None,
                modified=None) -> int:
@@ -118,6 +131,7 @@ class Engine:
         (indices, values) per row (host), or a CSR triple (off, idx, val) of NumPy arrays /
         device tensors matching ``dense``'s memory space. Returns the first assigned row."""
         if _is_device_tensor(dense):
+            self._follow(dense)
             mem = VR_MEM_DEVICE
             n = int(dense.shape[0])
             assert dense.is_contiguous() and tuple(dense.shape)[1] == self.dim
@@ -197,6 +211,7 @@ class Engine:
     def search_dense(self, queries, k: int, flt: SearchFilter | None = None):
         """-> list of (rows int64[c], scores f32[c]) per query."""
         if _is_device_tensor(queries):
+            self._follow(queries)
             mem, nq = VR_MEM_DEVICE, int(queries.shape[0])
             qp = C.c_void_p(queries.data_ptr())
         else:
@@ -227,6 +242,7 @@ class Engine:
                       fusion: int = VR_FUSION_MINMAX, flt: SearchFilter | None = None):
         """-> (rows int64[c], fused scores f64[c], from_dense int32[c])"""
         if _is_device_tensor(query):
+            self._follow(query)
             mem, qp = VR_MEM_DEVICE, C.c_void_p(query.data_ptr())
         else:
             q = _np(query, np.float32).reshape(self.dim)
