@@ -131,6 +131,32 @@ int vr_encoder_load(vr_engine* e, const vr_bert_desc* desc, const void* const* t
 int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t n_seq, int mem,
               float* out, int out_mem);
 
+/* ---- BM25 document side: replaces SparseTextEmbedding("Qdrant/bm25").embed's token-count / TF
+ * weighting (sparse_embedding.py:25,49; scripts/build_sparse_vectors.py:124,170) -- */
+/* tok_off: n_docs+1 offsets, tok_ids: abs(murmur3) of each stemmed token in text order (`mem`).
+ * Outputs (`mem`), padded layout: document d's distinct term ids, ascending, are
+ * out_idx[tok_off[d] .. tok_off[d] + out_cnt[d]) with tf weights (f64, the Python floats the
+ * reference passes on) at the same positions of out_val; out_idx/out_val hold tok_off[n_docs]
+ * entries. tf = c*(k+1) / (c + k*(1 - b + b*doc_len/avg_len)); fastembed defaults k=1.2 b=0.75
+ * avg_len=256. */
+int vr_bm25_tf(vr_engine* e, const int64_t* tok_off, const int32_t* tok_ids, int64_t n_docs, int mem,
+               double k, double b, double avg_len,
+               int32_t* out_cnt, int32_t* out_idx, double* out_val);
+
+/* ---- fused indexing step: the three starred calls of IndexingService._index_file_standard
+ * (src/voitta/services/indexing.py:527-530,560) — embed_texts, sparse embed_texts, store_chunks —
+ * without leaving HBM: encode (vr_encode) -> BM25 tf (vr_bm25_tf) -> store (vr_upsert).
+ * wp_ids / wp_off (int32, n+1): WordPiece ids per chunk; bm_ids / bm_off (int64 offsets, n+1):
+ * hashed stems per chunk, or both NULL for a dense-only index. Token arrays are in `mem`; the
+ * payload columns are host arrays as in vr_upsert. Needs a loaded encoder with hidden == dim. */
+int vr_index_batch(vr_engine* e, int64_t n, int mem,
+                   const int32_t* wp_ids, const int32_t* wp_off,
+                   const int32_t* bm_ids, const int64_t* bm_off,
+                   double k, double b, double avg_len,
+                   const int32_t* folder_id, const int32_t* index_folder_id,
+                   const int64_t* created, const int64_t* modified,
+                   int64_t* out_first_row);
+
 /* ---- index: replaces VectorStoreService.store_chunks' client.upsert (vector_store.py:291-313)
  * and the Qdrant-side cosine normalisation on insert (SURVEY.md a10 [EXT]). ------------------- */
 /* dense   : n x D f32 row-major

@@ -181,6 +181,12 @@ void vr_engine_destroy(vr_engine* e) {
   e->stage_i32b.release();
   e->stage_i64a.release();
   e->stage_i64b.release();
+  e->stage_f64.release();
+  e->bm_marks.release();
+  e->bm_cnt.release();
+  e->bm_idx.release();
+  e->bm_val.release();
+  e->enc_out.release();
   e->q_tiled.release();
   e->scores.release();
   e->sp_scores.release();
@@ -231,14 +237,15 @@ int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t 
   return encoder_encode(e, ids, offsets, n_seq, mem, out, out_mem);
 }
 
-int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
-              const int32_t* sp_idx, const float* sp_val, const int32_t* folder_id,
-              const int32_t* index_folder_id, const int64_t* created, const int64_t* modified,
-              int64_t* out_first_row) {
-  VR_TRY(check_engine(e));
-  VR_CHECK(n >= 0, "negative row count");
-  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+}  // extern "C"
+
+// Body of vr_upsert, also the last stage of vr_index_batch. Caller holds e->mu.
+// sp_cnt_dev (device memory, mem == VR_MEM_DEVICE only): when given, the sparse rows are in the
+// padded layout bm25_tf_kernel writes — row r = idx/val[sp_off[r] .. sp_off[r] + sp_cnt_dev[r]).
+static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
+                         const int32_t* sp_idx, const float* sp_val, const int32_t* sp_cnt_dev,
+                         const int32_t* folder_id, const int32_t* index_folder_id,
+                         const int64_t* created, const int64_t* modified, int64_t* out_first_row) {
   const int64_t first = e->n_rows;
   if (out_first_row) *out_first_row = first;
   if (n == 0) return 0;
@@ -332,13 +339,27 @@ int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_
                               hipMemcpyHostToDevice, e->stream));
       }
       VR_HIP(hipStreamSynchronize(e->stream));  // idx/val vectors die at scope end
-      VR_TRY(sparse_append(e, n, first, sp_off, e->stage_off.p, e->stage_idx.p, e->stage_val.p));
+      std::vector<int32_t> cnt(static_cast<size_t>(n));
+      for (int64_t r = 0; r < n; ++r) cnt[static_cast<size_t>(r)] = static_cast<int32_t>(sp_off[r + 1] - sp_off[r]);
+      VR_TRY(sparse_append(e, n, first, cnt.data(), e->stage_off.p, nullptr, e->stage_idx.p, e->stage_val.p));
+    } else if (sp_cnt_dev) {
+      std::vector<int32_t> cnt(static_cast<size_t>(n));
+      VR_HIP(hipMemcpyAsync(cnt.data(), sp_cnt_dev, sizeof(int32_t) * static_cast<size_t>(n),
+                            hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));
+      VR_TRY(sparse_append(e, n, first, cnt.data(), sp_off, sp_cnt_dev, sp_idx, sp_val));
     } else {
       std::vector<int64_t> off_host(static_cast<size_t>(n + 1));
       VR_HIP(hipMemcpyAsync(off_host.data(), sp_off, sizeof(int64_t) * static_cast<size_t>(n + 1),
                             hipMemcpyDeviceToHost, e->stream));
       VR_HIP(hipStreamSynchronize(e->stream));
-      VR_TRY(sparse_append(e, n, first, off_host.data(), sp_off, sp_idx, sp_val));
+      VR_CHECK(off_host[0] == 0, "sparse offsets must start at 0");
+      std::vector<int32_t> cnt(static_cast<size_t>(n));
+      for (int64_t r = 0; r < n; ++r) {
+        VR_CHECK(off_host[static_cast<size_t>(r) + 1] >= off_host[static_cast<size_t>(r)], "sparse offsets must be non-decreasing");
+        cnt[static_cast<size_t>(r)] = static_cast<int32_t>(off_host[static_cast<size_t>(r) + 1] - off_host[static_cast<size_t>(r)]);
+      }
+      VR_TRY(sparse_append(e, n, first, cnt.data(), sp_off, nullptr, sp_idx, sp_val));
     }
   }
   VR_HIP(hipGetLastError());
@@ -348,6 +369,73 @@ int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_
   e->n_rows += n;
   e->n_live += n;
   return 0;
+}
+
+extern "C" {
+
+int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
+              const int32_t* sp_idx, const float* sp_val, const int32_t* folder_id,
+              const int32_t* index_folder_id, const int64_t* created, const int64_t* modified,
+              int64_t* out_first_row) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n >= 0, "negative row count");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  return upsert_locked(e, n, mem, dense, sp_off, sp_idx, sp_val, nullptr, folder_id, index_folder_id,
+                       created, modified, out_first_row);
+}
+
+int vr_index_batch(vr_engine* e, int64_t n, int mem, const int32_t* wp_ids, const int32_t* wp_off,
+                   const int32_t* bm_ids, const int64_t* bm_off, double k, double b, double avg_len,
+                   const int32_t* folder_id, const int32_t* index_folder_id, const int64_t* created,
+                   const int64_t* modified, int64_t* out_first_row) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n >= 0 && (n == 0 || (wp_ids && wp_off)), "bad arguments");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  VR_CHECK((bm_ids == nullptr) == (bm_off == nullptr), "bm_ids and bm_off go together");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (n == 0) {
+    if (out_first_row) *out_first_row = e->n_rows;
+    return 0;
+  }
+  // 1. sparse side first: it is microseconds of work and its per-document counts are the only
+  //    thing the host has to wait for (slice widths); the long encode is queued behind it.
+  const int64_t* bm_off_dev = nullptr;
+  if (bm_off) {
+    int64_t n_tokens = 0;
+    const int32_t* bm_ids_dev = bm_ids;
+    bm_off_dev = bm_off;
+    if (mem == VR_MEM_HOST) {
+      VR_CHECK(bm_off[0] == 0, "token offsets must start at 0");
+      n_tokens = bm_off[n];
+      VR_TRY(e->stage_off.grow(n + 1, 0, e->stream));
+      VR_TRY(e->stage_idx.grow(std::max<int64_t>(n_tokens, 1), 0, e->stream));
+      VR_HIP(hipMemcpyAsync(e->stage_off.p, bm_off, sizeof(int64_t) * static_cast<size_t>(n + 1),
+                            hipMemcpyHostToDevice, e->stream));
+      if (n_tokens > 0)
+        VR_HIP(hipMemcpyAsync(e->stage_idx.p, bm_ids, sizeof(int32_t) * static_cast<size_t>(n_tokens),
+                              hipMemcpyHostToDevice, e->stream));
+      bm_off_dev = e->stage_off.p;
+      bm_ids_dev = e->stage_idx.p;
+    } else {
+      VR_HIP(hipMemcpyAsync(&n_tokens, bm_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));
+    }
+    const int64_t cap = std::max<int64_t>(n_tokens, 1);
+    VR_TRY(e->bm_cnt.grow(n, 0, e->stream));
+    VR_TRY(e->bm_idx.grow(cap, 0, e->stream));
+    VR_TRY(e->bm_val.grow(cap, 0, e->stream));
+    VR_TRY(bm25_tf(e, bm_off_dev, bm_ids_dev, n, n_tokens, k, b, avg_len, e->bm_cnt.p, e->bm_idx.p,
+                   nullptr, e->bm_val.p));
+  }
+  // 2. dense encode into engine-owned rows
+  VR_CHECK(encoder_hidden(e) == e->dim, "encoder width %d != store dimension %d", encoder_hidden(e), e->dim);
+  VR_TRY(e->enc_out.grow(n * e->dim, 0, e->stream));
+  VR_TRY(encoder_encode(e, wp_ids, wp_off, static_cast<int>(n), mem, e->enc_out.p, VR_MEM_DEVICE));
+  // 3. store
+  return upsert_locked(e, n, VR_MEM_DEVICE, e->enc_out.p, bm_off_dev, bm_off ? e->bm_idx.p : nullptr,
+                       bm_off ? e->bm_val.p : nullptr, bm_off ? e->bm_cnt.p : nullptr, folder_id,
+                       index_folder_id, created, modified, out_first_row);
 }
 
 int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n) {

@@ -477,6 +477,11 @@ void encoder_release(vr_engine* e) {
   e->encoder = nullptr;
 }
 
+int encoder_hidden(vr_engine* e) {
+  Encoder* enc = static_cast<Encoder*>(e->encoder);
+  return enc ? enc->d.hidden : 0;
+}
+
 int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int n_tensors, int mem) {
   VR_CHECK(d->struct_size == static_cast<int32_t>(sizeof(vr_bert_desc)), "vr_bert_desc size mismatch");
   const int H = d->hidden, I = d->intermediate, L = d->layers;

@@ -138,7 +138,13 @@ struct vr_engine {
   vr::DevArray<int32_t> stage_i32b;
   vr::DevArray<int64_t> stage_i64a;
   vr::DevArray<int64_t> stage_i64b;
-  vr::DevArray<float> q_tiled;        // 16-query image, kblocks KiB
+  vr::DevArray<double> stage_f64;
+  vr::DevArray<int32_t> bm_marks;     // bm25_tf_kernel scratch for documents longer than its LDS
+  vr::DevArray<int32_t> bm_cnt;       // vr_index_batch: per-document distinct terms
+  vr::DevArray<int32_t> bm_idx;       //                 padded term ids
+  vr::DevArray<float> bm_val;         //                 padded tf weights (f32, as stored)
+  vr::DevArray<float> enc_out;        //                 encoder output rows
+  vr::DevArray<float> q_tiled;       // 16-query image, kblocks KiB
   vr::DevArray<float> scores;         // [16][cap_rows]
   vr::DevArray<float> sp_scores;      // [cap_rows]
   vr::DevArray<uint8_t> mask;         // [cap_rows]
@@ -169,8 +175,14 @@ int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, in
                 const uint64_t** out_keys);
 
 // ---- sparse.hip
-int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int64_t* off_host,
-                  const int64_t* off_dev, const int32_t* idx_dev, const float* val_dev);
+// rows of the batch live at idx/val[begin[r] .. +count); count = cnt_dev[r] or begin[r+1]-begin[r]
+int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
+                  const int64_t* begin_dev, const int32_t* cnt_dev, const int32_t* idx_dev,
+                  const float* val_dev);
+// ---- bm25.hip
+int bm25_tf(vr_engine* e, const int64_t* tok_off_dev, const int32_t* tok_ids_dev, int64_t n_docs,
+            int64_t n_tokens, double k, double b, double avg_len, int32_t* out_cnt_dev,
+            int32_t* out_idx_dev, double* out_val64_dev, float* out_val32_dev);
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
                   const uint8_t* mask_dev);
 int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
@@ -182,6 +194,7 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* tensors
 int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int n_seq, int mem,
                    float* out, int out_mem);
 void encoder_release(vr_engine* e);
+int encoder_hidden(vr_engine* e);  // 0 when no encoder is loaded
 
 // ---- filter.hip
 // returns the device mask to use for this query (live[] when no filter is active)

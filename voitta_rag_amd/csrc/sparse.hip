@@ -74,12 +74,6 @@ __global__ void df_rehash_kernel(const int32_t* okeys, const int32_t* ocnt, int6
   if (i < ocap && okeys[i] != -1) df_add(keys, cnt, cap, okeys[i], ocnt[i], distinct);
 }
 
-__global__ void df_update_kernel(const int32_t* __restrict__ idx, int64_t nnz, int32_t* keys,
-                                 int32_t* cnt, int64_t cap, int32_t* distinct) {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < nnz) df_add(keys, cnt, cap, idx[i], 1, distinct);
-}
-
 static int df_ensure(vr_engine* e, int64_t incoming) {
   if (e->df_cap == 0) {
     e->df_cap = 1 << 20;
@@ -123,12 +117,15 @@ static int df_ensure(vr_engine* e, int64_t incoming) {
 
 // ---- SELL-64 build ----------------------------------------------------------------------------
 
-// One wave per slice; lane l copies CSR row (first + l) into its SELL column, padding with -1.
-// Rows must already be sorted by token id (vr_upsert sorts host input; the device BM25 kernel
-// emits sorted rows).
+// One wave per slice; lane l copies row (row_base + l) of the batch into its SELL column, padding
+// with -1. The row's entries are idx/val[begin[r] .. begin[r] + count) where count is cnt[r] when
+// cnt is given (padded layout written by bm25_tf_kernel) and begin[r+1] - begin[r] otherwise
+// (plain CSR). Rows must already be sorted by token id (vr_upsert sorts host input; the device
+// BM25 kernel emits sorted rows).
 __global__ __launch_bounds__(64) void sell_build_kernel(const SliceDesc* __restrict__ slices,
                                                         int64_t slice0, int64_t batch_first_row,
-                                                        const int64_t* __restrict__ off,
+                                                        const int64_t* __restrict__ begin,
+                                                        const int32_t* __restrict__ cnt,
                                                         const int32_t* __restrict__ idx,
                                                         const float* __restrict__ val,
                                                         int32_t* __restrict__ sidx,
@@ -136,27 +133,41 @@ __global__ __launch_bounds__(64) void sell_build_kernel(const SliceDesc* __restr
                                                         int32_t* __restrict__ row_slice) {
   const SliceDesc d = slices[slice0 + blockIdx.x];
   const int lane = threadIdx.x;
-  int64_t begin = 0, end = 0;
+  int64_t b0 = 0;
+  int len = 0;
   if (lane < d.nrows) {
     int64_t local = d.row_base + lane - batch_first_row;
-    begin = off[local];
-    end = off[local + 1];
+    b0 = begin[local];
+    len = cnt ? cnt[local] : static_cast<int>(begin[local + 1] - b0);
     row_slice[d.row_base + lane] = static_cast<int32_t>(slice0 + blockIdx.x);
   }
-  const int len = static_cast<int>(end - begin);
   for (int j = 0; j < d.width; ++j) {
     int64_t dst = d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3);
     bool has = j < len;
-    sidx[dst] = has ? idx[begin + j] : -1;
-    sval[dst] = has ? val[begin + j] : 0.0f;
+    sidx[dst] = has ? idx[b0 + j] : -1;
+    sval[dst] = has ? val[b0 + j] : 0.0f;
   }
 }
 
-int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int64_t* off_host,
-                  const int64_t* off_dev, const int32_t* idx_dev, const float* val_dev) {
+// +1 document frequency for every real entry of the freshly built slices
+__global__ void df_update_region_kernel(const int32_t* __restrict__ sidx, int64_t begin, int64_t end,
+                                        int32_t* keys, int32_t* cnt, int64_t cap, int32_t* distinct) {
+  int64_t i = begin + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < end) {
+    int32_t id = sidx[i];
+    if (id >= 0) df_add(keys, cnt, cap, id, 1, distinct);
+  }
+}
+
+int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
+                  const int64_t* begin_dev, const int32_t* cnt_dev, const int32_t* idx_dev,
+                  const float* val_dev) {
   if (n <= 0) return 0;
-  const int64_t nnz = off_host[n] - off_host[0];
-  VR_CHECK(off_host[0] == 0, "sparse offsets must start at 0");
+  int64_t nnz = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    VR_CHECK(cnt_host[r] >= 0, "negative sparse row length");
+    nnz += cnt_host[r];
+  }
   VR_TRY(df_ensure(e, nnz));
 
   const int64_t slice0 = static_cast<int64_t>(e->slices_host.size());
@@ -166,28 +177,29 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int64_t* off
     d.off = used;
     d.row_base = static_cast<int32_t>(first_row + r);
     d.nrows = static_cast<int32_t>(std::min<int64_t>(64, n - r));
-    int64_t w = 0;
-    for (int i = 0; i < d.nrows; ++i) w = std::max(w, off_host[r + i + 1] - off_host[r + i]);
-    d.width = static_cast<int32_t>((w + 3) / 4 * 4);
+    int32_t w = 0;
+    for (int i = 0; i < d.nrows; ++i) w = std::max(w, cnt_host[r + i]);
+    d.width = (w + 3) / 4 * 4;
     d.pad = 0;
     used += static_cast<int64_t>(d.width) * 64;
     e->slices_host.push_back(d);
   }
   const int64_t n_new = static_cast<int64_t>(e->slices_host.size()) - slice0;
-  VR_TRY(e->sp_idx.grow(used, e->sp_used, e->stream));
-  VR_TRY(e->sp_val.grow(used, e->sp_used, e->stream));
+  VR_TRY(e->sp_idx.grow(std::max<int64_t>(used, 1), e->sp_used, e->stream));
+  VR_TRY(e->sp_val.grow(std::max<int64_t>(used, 1), e->sp_used, e->stream));
   VR_TRY(e->slices.grow(static_cast<int64_t>(e->slices_host.size()), slice0, e->stream));
   VR_HIP(hipMemcpyAsync(e->slices.p + slice0, e->slices_host.data() + slice0,
                         sizeof(SliceDesc) * static_cast<size_t>(n_new), hipMemcpyHostToDevice,
                         e->stream));
   VR_HIP(hipStreamSynchronize(e->stream));  // slices_host may reallocate on the next append
   hipLaunchKernelGGL(sell_build_kernel, dim3(static_cast<unsigned>(n_new)), dim3(64), 0, e->stream,
-                     e->slices.p, slice0, first_row, off_dev, idx_dev, val_dev, e->sp_idx.p,
+                     e->slices.p, slice0, first_row, begin_dev, cnt_dev, idx_dev, val_dev, e->sp_idx.p,
                      e->sp_val.p, e->row_slice.p);
-  if (nnz > 0)
-    hipLaunchKernelGGL(df_update_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256),
-                       0, e->stream, idx_dev, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
-                       e->df_distinct);
+  const int64_t region = used - e->sp_used;
+  if (region > 0)
+    hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((region + 255) / 256)),
+                       dim3(256), 0, e->stream, e->sp_idx.p, e->sp_used, used, e->df_keys.p,
+                       e->df_cnt.p, e->df_cap, e->df_distinct);
   VR_HIP(hipGetLastError());
   e->sp_used = used;
   e->n_slices_dev = static_cast<int64_t>(e->slices_host.size());

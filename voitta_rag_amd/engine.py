@@ -178,6 +178,56 @@ class Engine:
                                   C.byref(first)))
         return int(first.value)
 
+    # ---- BM25 / fused indexing ------------------------------------------------------------
+    BM25_K, BM25_B, BM25_AVG_LEN = 1.2, 0.75, 256.0  # fastembed Qdrant/bm25 defaults [EXT]
+
+    def bm25_tf(self, tok_off, tok_ids, k: float = BM25_K, b: float = BM25_B, avg_len: float = BM25_AVG_LEN):
+        """Hashed stems per document (host arrays) -> [(indices int32 asc, values f64)] per document."""
+        off = _np(tok_off, np.int64)
+        ids = _np(tok_ids, np.int32)
+        n = off.shape[0] - 1
+        cnt = np.zeros(max(n, 0), np.int32)
+        idx = np.zeros(max(int(off[-1]) if n >= 0 else 0, 1), np.int32)
+        val = np.zeros(idx.shape[0], np.float64)
+        check(self._lib.vr_bm25_tf(self._h, C.c_void_p(off.ctypes.data), C.c_void_p(ids.ctypes.data), n, VR_MEM_HOST,
+                                   k, b, avg_len, C.c_void_p(cnt.ctypes.data), C.c_void_p(idx.ctypes.data),
+                                   C.c_void_p(val.ctypes.data)))
+        return [(idx[off[d]: off[d] + cnt[d]].copy(), val[off[d]: off[d] + cnt[d]].copy()) for d in range(n)]
+
+    def index_batch(self, wp_ids, wp_off, bm_ids=None, bm_off=None, folder_ids=None, index_folder_ids=None,
+                    created=None, modified=None, k: float = BM25_K, b: float = BM25_B,
+                    avg_len: float = BM25_AVG_LEN) -> int:
+        """encode -> BM25 tf -> store, all on the GPU. Token arrays are NumPy (host) or device tensors."""
+        dev = _is_device_tensor(wp_ids)
+        if dev:
+            self._follow(wp_ids)
+            n = int(wp_off.shape[0]) - 1
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)  # noqa: E731
+            keep = [wp_ids, wp_off, bm_ids, bm_off]
+            args = [ptr(wp_ids), ptr(wp_off), ptr(bm_ids), ptr(bm_off)]
+        else:
+            wp_ids, wp_off = _np(wp_ids, np.int32), _np(wp_off, np.int32)
+            n = wp_off.shape[0] - 1
+            if bm_ids is not None:
+                bm_ids, bm_off = _np(bm_ids, np.int32), _np(bm_off, np.int64)
+            keep = [wp_ids, wp_off, bm_ids, bm_off]
+            args = [C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(None) for a in keep]
+
+        def col(a, dtype, ctype):
+            if a is None:
+                return None
+            a = _np(a, dtype)
+            assert a.shape == (n,)
+            keep.append(a)
+            return _ptr(a, ctype)
+
+        first = C.c_int64(-1)
+        check(self._lib.vr_index_batch(self._h, n, VR_MEM_DEVICE if dev else VR_MEM_HOST, *args, k, b, avg_len,
+                                       col(folder_ids, np.int32, C.c_int32), col(index_folder_ids, np.int32, C.c_int32),
+                                       col(created, np.int64, C.c_int64), col(modified, np.int64, C.c_int64),
+                                       C.byref(first)))
+        return int(first.value)
+
     def delete_rows(self, rows) -> None:
         r = _np(rows, np.int64)
         check(self._lib.vr_delete_rows(self._h, _ptr(r, C.c_int64), r.shape[0]))
