@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Contract benchmark of the voitta-rag hot path on MI355X.
+
+Metric (BASELINE.json): chunks indexed/sec + p50 top-10 query latency @ 1M-chunk corpus, one GPU.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU):
+  1M-chunk corpus, bge-base-en-v1.5 shape (L12 H768 12 heads, CLS pooling) dense + BM25 sparse,
+  hybrid top-10 (prefetch 30 per modality; the reference's min-max weighted fusion,
+  vector_store.py:621-697 — SURVEY.md F3 explains why not RRF).
+
+A STEP = one pass of the indexing hot path over one batch of synthetic chunks whose token ids are
+already resident in HBM: dense encode (HIP BERT forward) -> BM25 token-count/TF weighting -> store
+(cosine preprocess + MFMA-tiled corpus append + SELL sparse append + document frequencies) — the
+three starred calls of IndexingService._index_file_standard (indexing.py:527-530,560) fused in
+vr_index_batch. `value` = chunks/s over EXACTLY --steps such steps, max over ranks.
+After the timed steps the query side is measured on the same engine (>= 1M rows per GPU):
+single-stream hybrid top-10 queries, p50/p99 of the wall time per query.
+
+Weak scaling: every rank owns its own 1M-row shard and indexes its own batches (no collective on
+the indexing path); queries merge per-shard top-k lists with one RCCL all_gather per list.
+
+Data: synthetic (seeded), weights random-init N(0, 0.02) of the named architecture — there is no
+network for checkpoints. dtype f32: every product runs on the f32-input MFMA (exact f32).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL = dict(name="bge-base-en-v1.5", layers=12, hidden=768, heads=12, intermediate=3072, vocab=30522,
+             max_pos=512, pooling="cls")
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_HBM_GBPS = 8000.0         # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy rate)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--batch", type=int, default=2048, help="chunks per step per GPU")
+    p.add_argument("--corpus", type=int, default=1_000_000, help="pre-populated rows per GPU")
+    p.add_argument("--queries", type=int, default=1000)
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def zipf_ids(gen, torch, n, vocab, dev, s=1.07):
+    """Zipf(s)-like draw over [0, vocab) on the device (inverse-CDF of a continuous power law)."""
+    u = torch.rand(n, device=dev, generator=gen)
+    x = ((vocab ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))
+    return (x - 1.0).clamp_(0, vocab - 1).to(torch.int64)
+
+
+def stem_hash(torch, ids):
+    """deterministic 31-bit id per synthetic stem (stands in for abs(murmur3(stem)))"""
+    h = (ids * 2654435761 + 0x9E3779B9) & 0xFFFFFFFF
+    h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+    return (h & 0x7FFFFFFF).to(torch.int32)
+
+
+def make_batch(torch, gen, dev, n_chunks, seed_shift):
+    """One step's input, device resident: WordPiece ids (~118 per chunk incl. [CLS]/[SEP], the length
+    of the reference's 512-character chunks) and hashed BM25 stems (~48 per chunk)."""
+    lens = torch.randint(96, 141, (n_chunks,), device=dev, generator=gen)
+    wp_off = torch.zeros(n_chunks + 1, dtype=torch.int32, device=dev)
+    wp_off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    T = int(wp_off[-1])
+    wp = (zipf_ids(gen, torch, T, MODEL["vocab"] - 1000, dev) + 999).to(torch.int32)
+    wp[wp_off[:-1].long()] = 101            # [CLS]
+    wp[(wp_off[1:] - 1).long()] = 102       # [SEP]
+    blens = torch.randint(36, 61, (n_chunks,), device=dev, generator=gen)
+    bm_off = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
+    bm_off[1:] = torch.cumsum(blens, 0)
+    bm = stem_hash(torch, zipf_ids(gen, torch, int(bm_off[-1]), 30000, dev))
+    return wp.contiguous(), wp_off.contiguous(), bm.contiguous(), bm_off.contiguous(), T
+
+
+def random_state(torch, gen, dev):
+    from voitta_rag_amd import encoder as enc
+
+    H, I = MODEL["hidden"], MODEL["intermediate"]
+    state = {}
+    for n in enc.tensor_names(MODEL["layers"]):
+        if n.endswith("word_embeddings.weight"): shp = (MODEL["vocab"], H)
+        elif n.endswith("position_embeddings.weight"): shp = (MODEL["max_pos"], H)
+        elif n.endswith("token_type_embeddings.weight"): shp = (2, H)
+        elif n.endswith("intermediate.dense.weight"): shp = (I, H)
+        elif n.endswith("intermediate.dense.bias"): shp = (I,)
+        elif n.endswith("output.dense.weight") and "attention" not in n: shp = (H, I)
+        elif n.endswith(".weight") and "LayerNorm" not in n: shp = (H, H)
+        else: shp = (H,)
+        t = torch.randn(shp, device=dev, generator=gen) * 0.02
+        if "LayerNorm.weight" in n:
+            t = t + 1.0
+        state[n] = t
+    return state
+
+
+def populate(torch, gen, dev, engine, rows, dim):
+    """Search corpus generated directly on the device as seeded unit vectors + synthetic BM25 rows
+    (SURVEY.md §8d allows this for the search side). Returns the dense tensor for the recall check."""
+    keep = []
+    chunk = 100_000
+    nnz = 40
+    ar = torch.arange(nnz, device=dev, dtype=torch.int64)[None, :]
+    for a in range(0, rows, chunk):
+        n = min(chunk, rows - a)
+        x = torch.nn.functional.normalize(torch.randn((n, dim), device=dev, generator=gen), dim=1).contiguous()
+        stems = zipf_ids(gen, torch, n * nnz, 30000, dev).view(n, nnz)
+        stems, _ = torch.sort(stems, dim=1)
+        stems = stems * 64 + ar                       # distinct inside a row, still ascending
+        ids, _ = torch.sort(stem_hash(torch, stems).to(torch.int64), dim=1)
+        dup = torch.zeros_like(ids, dtype=torch.bool)
+        dup[:, 1:] = ids[:, 1:] == ids[:, :-1]
+        ids = torch.where(dup, ids + 1, ids)          # (rare) hash collisions inside a row
+        ids, _ = torch.sort(ids, dim=1)
+        off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * nnz).contiguous()
+        val = (torch.rand(n * nnz, device=dev, generator=gen) * 1.6 + 0.4).contiguous()
+        engine.upsert(x, sparse=(off, ids.to(torch.int32).reshape(-1).contiguous(), val))
+        keep.append(x)
+    return keep
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: cgroup quota and affinity, not the machine's count
+    (a 1-GPU box exposes 256 logical CPUs but schedules a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("VR_BENCH_CPU_THREADS")
+    return int(env) if env else min(n, 16)  # 16 = the CPU share of one GPU on the bench box
+
+
+def cpu_baseline(args, rng):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload."""
+    import torch
+
+    from oracle import bert as obert
+    from oracle import bert_torch
+    from oracle import bm25 as obm
+    from oracle import core as ocore
+
+    torch.set_num_threads(host_cores())
+    shape = obert.BertShape(MODEL["layers"], MODEL["hidden"], MODEL["heads"], MODEL["intermediate"],
+                            vocab=MODEL["vocab"], max_pos=MODEL["max_pos"])
+    model = bert_torch.TorchBert(obert.random_weights(shape, 7), shape, MODEL["pooling"])
+    model.encode([rng.integers(999, MODEL["vocab"], size=16).astype(np.int32) for _ in range(4)])  # thread-pool warm-up
+    done, t_used = 0, 0.0
+    while t_used < args.cpu_seconds and done < 4096:
+        seqs = [rng.integers(999, MODEL["vocab"], size=int(rng.integers(96, 141))).astype(np.int32) for _ in range(32)]
+        stems = [rng.integers(0, 1 << 31, size=int(rng.integers(36, 61))).tolist() for _ in range(32)]
+        t0 = time.perf_counter()
+        emb = model.encode(seqs, batch_size=32)           # embed_texts
+        sp = [obm.tf_from_hashed(s) for s in stems]       # sparse embed_texts (token-count / tf)
+        ocore.cosine_preprocess(emb)                      # store: Qdrant-side normalisation
+        t_used += time.perf_counter() - t0
+        done += 32
+        del sp
+    chunks_per_s = done / t_used
+    # query side: exact f32 brute force (NumPy/BLAS on all threads) over a sample of the corpus
+    rows = 200_000
+    x = rng.standard_normal((rows, MODEL["hidden"]), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    lat = []
+    for _ in range(12):
+        q = rng.standard_normal(MODEL["hidden"], dtype=np.float32)
+        t0 = time.perf_counter()
+        sc = x @ q
+        top = np.argpartition(-sc, 30)[:30]
+        top[np.argsort(-sc[top])]
+        lat.append(time.perf_counter() - t0)
+    q_ms = float(np.median(lat[2:]) * 1e3 * (args.corpus / rows))
+    return {
+        "value": round(chunks_per_s, 2), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{done} chunks (batches of 32, 96-140 tokens) through oracle/bert_torch.py (torch-CPU f32, "
+                  f"{MODEL['name']} shape, all host threads) + oracle BM25 tf + oracle cosine preprocess, {t_used:.1f} s",
+        "query_p50_ms": round(q_ms, 2),
+        "query_sample": f"exact f32 dense scan (NumPy matmul + partial sort, all threads) over {rows} of "
+                        f"{args.corpus} rows, time scaled x{args.corpus // rows}; sparse scan and fusion not included",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from voitta_rag_amd import Engine
+    from voitta_rag_amd import encoder as enc
+
+    dim = MODEL["hidden"]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    engine = Engine(dim, device=local_rank, initial_rows=args.corpus + (args.steps + args.warmup) * args.batch + 64)
+    enc.load_encoder(engine, enc.BertDesc(MODEL["layers"], dim, MODEL["heads"], MODEL["intermediate"],
+                                          vocab=MODEL["vocab"], max_pos=MODEL["max_pos"], pooling=MODEL["pooling"]),
+                     random_state(torch, gen, dev))
+    corpus_chunks = populate(torch, gen, dev, engine, args.corpus, dim)
+    batches = [make_batch(torch, gen, dev, args.batch, i) for i in range(args.warmup + args.steps)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- indexing: W warm-up steps, then exactly K timed steps ------------------------------------
+    for b in batches[: args.warmup]:
+        engine.index_batch(b[0], b[1], b[2], b[3])
+    engine.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    tokens = 0
+    for b in batches[args.warmup:]:
+        engine.index_batch(b[0], b[1], b[2], b[3])
+        tokens += b[4]
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_flop = engine.profile_read(Engine.PROF_GEMM)
+    attn_ms, attn_n, attn_flop = engine.profile_read(Engine.PROF_ATTENTION)
+    engine.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    chunks_per_s = world * args.steps * args.batch / dt
+
+    # ---- queries: single stream, hybrid top-10 over >= corpus rows per GPU ------------------------
+    n_rows, _ = engine.count()
+    qgen = torch.Generator(device=dev).manual_seed(99)   # same queries on every rank
+    qs = torch.nn.functional.normalize(torch.randn((args.queries + 20, dim), device=dev, generator=qgen), dim=1)
+    qs_host = qs.cpu().numpy()
+    q_terms = stem_hash(torch, zipf_ids(qgen, torch, (args.queries + 20) * 6, 30000, dev)).view(-1, 6).cpu().numpy()
+    q_nnz = np.random.default_rng(5).integers(4, 7, size=args.queries + 20)
+    ones = np.ones(8, np.float32)
+    if world > 1:
+        from voitta_rag_amd.sharded import ShardedSearcher
+
+        searcher = ShardedSearcher(engine)
+        search = lambda i: searcher.search_hybrid(qs_host[i], q_terms[i, : q_nnz[i]], ones[: q_nnz[i]], 10, 0.1)  # noqa: E731
+    else:
+        search = lambda i: engine.search_hybrid(qs_host[i], q_terms[i, : q_nnz[i]], ones[: q_nnz[i]], 10, 0.1)  # noqa: E731
+    for i in range(20):
+        search(i)
+    engine.profile(True)
+    barrier()
+    lat = np.empty(args.queries)
+    for i in range(args.queries):
+        t1 = time.perf_counter()
+        search(20 + i)
+        lat[i] = time.perf_counter() - t1
+    barrier()
+    scan_ms, scan_n, scan_bytes = engine.profile_read(Engine.PROF_DENSE_SCAN)
+    sp_ms, sp_n, sp_bytes = engine.profile_read(Engine.PROF_SPARSE_SCAN)
+    engine.profile(False)
+    p50, p99 = float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3)
+    if world > 1:
+        t = torch.tensor([p50, p99], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        p50, p99 = float(t[0]), float(t[1])
+    dense_only = [engine.search_dense(qs_host[20 + i: 21 + i], 10) for i in range(min(50, args.queries))]
+
+    # ---- recall@10 of the dense scan against a plain torch f32 matmul over the same vectors ------
+    recall = None
+    if rank == 0:
+        hits = 0
+        nq = len(dense_only)
+        xs = torch.cat(corpus_chunks)  # rows 0 .. corpus-1 of this rank's engine
+        for i in range(nq):
+            ref = torch.topk(xs @ qs[20 + i], 10).indices.cpu().numpy()
+            got = dense_only[i][0][0]
+            got = got[got < args.corpus]  # rows indexed by the timed steps are not in `xs`
+            hits += len(set(ref.tolist()) & set(got.tolist()))
+        recall = hits / (10.0 * nq)
+    del corpus_chunks
+
+    if rank == 0:
+        gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        scan_gbps = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "chunks indexed/sec + p50 top-10 query latency @1M-chunk corpus, 1/8 MI355X",
+            "value": round(chunks_per_s, 1),
+            "unit": "chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded token ids / unit vectors; random-init N(0,0.02) weights of the named shape)",
+            "config": {
+                "workload": "BASELINE configs[2]: 1M-chunk corpus, bge-base-en-v1.5 shape (L12 H768 CLS) dense + "
+                            "BM25 sparse, min-max hybrid top-10 (prefetch 30), 1 MI355X per shard",
+                "chunks_per_step_per_gpu": args.batch,
+                "tokens_per_chunk_mean": round(tokens / (args.steps * args.batch), 1),
+                "corpus_rows_per_gpu": int(n_rows),
+                "queries": args.queries,
+                "fusion": "minmax (reference vector_store.py:659-689)",
+                "parallelism": f"shard{world}",
+            },
+            "p50_query_ms": round(p50, 4),
+            "p99_query_ms": round(p99, 4),
+            "query_kind": "single-stream hybrid top-10 (dense top-30 + sparse top-30 + fusion), query vector given",
+            "recall_at_10_dense_vs_torch_matmul": recall,
+            "roofline": {
+                "kernel": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma",
+                "achieved": round(gemm_tf, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(gemm_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "launches": gemm_n,
+                "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                "share_of_step_time": round(gemm_ms * 1e-3 / dt, 4),
+            },
+            "roofline_search": {
+                "kernel": "vr::dense_scores_kernel (v_mfma_f32_16x16x4_f32 streaming scan)",
+                "bound": "hbm",
+                "achieved": round(scan_gbps, 1),
+                "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s",
+                "frac": round(scan_gbps / PEAK_HBM_GBPS, 4),
+                "traffic": None,
+                "launches": scan_n,
+                "avg_launch_ms": round(scan_ms / max(scan_n, 1), 4),
+                "sparse_scan_avg_ms": round(sp_ms / max(sp_n, 1), 4),
+                "sparse_scan_GBps": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1) if sp_ms > 0 else None,
+            },
+            "attention": {"avg_launch_ms": round(attn_ms / max(attn_n, 1), 4),
+                          "TFLOPs": round(attn_flop / (attn_ms * 1e-3) / 1e12, 2) if attn_ms > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, np.random.default_rng(3))
+            out["speedup_vs_cpu_index"] = round(chunks_per_s / out["cpu_baseline"]["value"], 1)
+            out["speedup_vs_cpu_query"] = round(out["cpu_baseline"]["query_p50_ms"] / p50, 1)
+        print(json.dumps(out), flush=True)
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,8 +200,23 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
  * ascending token-id order, idf(t) = ln(1 + (N - df_t + 0.5)/(df_t + 0.5)); rows sharing no
  * term are not returned. */
 int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int32_t nnz,
-                     int32_t k, const vr_filter* filter,
+                     int32_t k, int32_t weights_given, const vr_filter* filter,
                      int64_t* rows, float* scores, int32_t* count);
+/* weights_given != 0: q_val[t] already is q_t * idf(t) and the engine applies no IDF. Used when
+ * the corpus is sharded over several engines (one per GPU): the caller all-reduces the document
+ * frequencies of the query terms (vr_sparse_stats) and computes idf with vr_idf, so that every
+ * shard scores with the collection-wide statistic. */
+float vr_idf(int64_t n_points, int32_t df);
+
+/* ---- measurement: HIP-event timing of the engine's own kernels on its stream ---------------- */
+#define VR_PROF_GEMM 0         /* encoder GEMMs; work = FLOP (2*M*N*K) */
+#define VR_PROF_ATTENTION 1    /* work = FLOP (4 * H * sum len^2) */
+#define VR_PROF_DENSE_SCAN 2   /* work = bytes (N*D*4 + masks + scores) */
+#define VR_PROF_SPARSE_SCAN 3  /* work = bytes (4 per stored id + 5 per row) */
+/* enable != 0 clears earlier records and starts recording one event pair per launch */
+int vr_profile(vr_engine* e, int enable);
+int vr_profile_read(vr_engine* e, int kernel_class, double* total_ms, int64_t* launches,
+                    double* total_work);
 
 /* hybrid: restates VectorStoreService._hybrid_search (vector_store.py:621-697): dense and sparse
  * top-(3*limit), min-max normalisation, (1-w)*d + w*s over the id union, top-`limit`.

@@ -41,3 +41,14 @@ def test_numpy_restatement_matches_transformers(path):
 
 def test_golden_files_present():
     assert len(GOLDEN) >= 4
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_torch_cpu_baseline_matches_golden(path):
+    """oracle/bert_torch.py is what bench.py times as cpu_baseline: it must compute the same thing."""
+    from oracle import bert_torch
+
+    shape, pooling, seed, seqs, want = load_case(path)
+    got = bert_torch.TorchBert(obert.random_weights(shape, seed), shape, pooling).encode(seqs, batch_size=3)
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
+    assert np.all(np.abs(1.0 - cos) < 1e-6) and np.max(np.abs(got - want)) < 2e-5

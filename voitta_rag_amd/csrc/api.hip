@@ -90,8 +90,9 @@ static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k,
 }
 
 static int search_sparse_block(vr_engine* e, const int32_t* q_idx, const float* q_val, int nnz, int k,
-                               const uint8_t* mask, uint64_t* host_keys /* pinned, k */) {
-  VR_TRY(sparse_scores(e, q_idx, q_val, nnz, mask));
+                               const uint8_t* mask, bool weights_given,
+                               uint64_t* host_keys /* pinned, k */) {
+  VR_TRY(sparse_scores(e, q_idx, q_val, nnz, mask, weights_given));
   const uint64_t* keys = nullptr;
   VR_TRY(topk_select(e, e->sp_scores.p, e->cap_rows, e->n_rows, 1, k, &keys));
   VR_HIP(hipMemcpyAsync(host_keys, keys, sizeof(uint64_t) * static_cast<size_t>(k),
@@ -159,6 +160,7 @@ void vr_engine_destroy(vr_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   encoder_release(e);
+  prof_release(e);
   e->corpus.release();
   e->live.release();
   e->folder.release();
@@ -539,7 +541,8 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
 }
 
 int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int32_t nnz, int32_t k,
-                     const vr_filter* filter, int64_t* rows, float* scores, int32_t* count) {
+                     int32_t weights_given, const vr_filter* filter, int64_t* rows, float* scores,
+                     int32_t* count) {
   VR_TRY(check_engine(e));
   VR_CHECK(rows && scores && count, "bad arguments");
   VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
@@ -554,7 +557,7 @@ int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
   uint64_t* host_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
-  VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, host_keys));
+  VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given != 0, host_keys));
   VR_HIP(hipStreamSynchronize(e->stream));
   *count = static_cast<int32_t>(decode_keys(host_keys, k, rows, scores));
   return 0;
@@ -588,7 +591,7 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
   if (have_sparse) {
     VR_CHECK(q_idx && q_val, "null sparse query");
-    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, sparse_keys));
+    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, false, sparse_keys));
   }
   VR_HIP(hipStreamSynchronize(e->stream));
   int64_t d_rows[kMaxK], s_rows[kMaxK];

@@ -182,10 +182,14 @@ int dense_scores(vr_engine* e, int nq, const uint8_t* mask_dev) {
   size_t lds = static_cast<size_t>(e->kblocks) * 1024;
   int64_t blocks = (n_tiles + 3) / 4;
   if (blocks > 2048) blocks = 2048;
+  // algorithmic bytes of one pass: the corpus rows once (N * D * 4) plus the mask and the scores
+  prof_begin(e, VR_PROF_DENSE_SCAN,
+             static_cast<double>(e->n_rows) * (e->dim * 4.0 + 1.0 + 4.0 * nq));
   hipLaunchKernelGGL(dense_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds,
                      e->stream, reinterpret_cast<const float4*>(e->corpus.p),
                      reinterpret_cast<const float4*>(e->q_tiled.p), mask_dev, e->scores.p, n_tiles,
                      e->kblocks, e->cap_rows, nq);
+  prof_end(e);
   VR_HIP(hipGetLastError());
   return 0;
 }

@@ -313,11 +313,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
-static int launch_gemm(hipStream_t s, int epi, const float* A, const float* W, const float* bias,
+static int launch_gemm(vr_engine* e, int epi, const float* A, const float* W, const float* bias,
                        const float* R, float* C, int M, int N, int K) {
   VR_CHECK(N % BN == 0 && K % BK == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, BN, BK);
   if (M <= 0) return 0;
+  hipStream_t s = e->stream;
   const int grid = ((M + BM - 1) / BM) * (N / BN);
+  prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
   switch (epi) {
     case EPI_BIAS:
       hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, A, W, bias, R, C, M, N, K);
@@ -329,6 +331,7 @@ static int launch_gemm(hipStream_t s, int epi, const float* A, const float* W, c
       hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS_RESIDUAL>), dim3(grid), dim3(256), 0, s, A, W, bias, R, C, M, N, K);
       break;
   }
+  prof_end(e);
   VR_HIP(hipGetLastError());
   return 0;
 }
@@ -552,7 +555,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
 // forward of sequences [seq0, seq1) whose tokens are ids_dev[tok_base .. tok_base + T)
 static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, const int32_t* cu_dev,
                          int n_seq_total, int seq0, int seq1, int tok_base, int T, int max_len,
-                         float* out_dev) {
+                         double attn_flop, float* out_dev) {
   const vr_bert_desc& d = enc->d;
   const int H = d.hidden, I = d.intermediate, nh = d.heads, dh = H / nh;
   hipStream_t s = e->stream;
@@ -563,19 +566,21 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   const int qblocks = (max_len + 63) / 64;
   const float scale = 1.0f / sqrtf(static_cast<float>(dh));
   for (const LayerWeights& w : enc->layers) {
-    VR_TRY(launch_gemm(s, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
+    VR_TRY(launch_gemm(e, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
     dim3 agrid(static_cast<unsigned>((seq1 - seq0) * qblocks), static_cast<unsigned>(nh));
+    prof_begin(e, VR_PROF_ATTENTION, attn_flop);
     if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
                          qblocks, scale, enc->ctx);
     else
       hipLaunchKernelGGL((attention_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
                          qblocks, scale, enc->ctx);
-    VR_TRY(launch_gemm(s, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
+    prof_end(e);
+    VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln1g, w.ln1b,
                        d.eps, enc->x);
-    VR_TRY(launch_gemm(s, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
-    VR_TRY(launch_gemm(s, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
+    VR_TRY(launch_gemm(e, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
+    VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln2g, w.ln2b,
                        d.eps, enc->x);
   }
@@ -631,16 +636,18 @@ int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int
     int seq1 = seq0;
     int max_len = 0;
     int64_t T = 0;
+    double len2 = 0.0;
     while (seq1 < n_seq) {
       int len = cu_host[static_cast<size_t>(seq1) + 1] - cu_host[static_cast<size_t>(seq1)];
       if (seq1 > seq0 && T + len > kMaxChunkTokens) break;
       T += len;
+      len2 += static_cast<double>(len) * len;
       max_len = std::max(max_len, len);
       ++seq1;
     }
     VR_TRY(ensure_workspace(e, enc, std::max<int64_t>(T, 1024)));
     VR_TRY(forward_chunk(e, enc, ids_dev, cu_dev, n_seq, seq0, seq1, cu_host[static_cast<size_t>(seq0)],
-                         static_cast<int>(T), max_len, out_dev));
+                         static_cast<int>(T), max_len, 4.0 * H * len2, out_dev));
     seq0 = seq1;
   }
   if (out_mem == VR_MEM_HOST) {

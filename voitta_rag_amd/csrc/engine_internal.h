@@ -157,8 +157,10 @@ struct vr_engine {
   void* pinned = nullptr;  // host pinned scratch for small D2H results
   size_t pinned_bytes = 0;
 
-  void* encoder = nullptr;  // vr::Encoder (encoder.hip)
+  void* encoder = nullptr;   // vr::Encoder (encoder.hip)
+  void* profiler = nullptr;  // vr::Profiler (profile.hip)
 };
+
 
 namespace vr {
 
@@ -184,7 +186,7 @@ int bm25_tf(vr_engine* e, const int64_t* tok_off_dev, const int32_t* tok_ids_dev
             int64_t n_tokens, double k, double b, double avg_len, int32_t* out_cnt_dev,
             int32_t* out_idx_dev, double* out_val64_dev, float* out_val32_dev);
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
-                  const uint8_t* mask_dev);
+                  const uint8_t* mask_dev, bool weights_given);
 int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
                        int64_t* n_sparse_deleted);
 int sparse_lookup_df(vr_engine* e, const int32_t* ids_host, int n, int32_t* out_df_host);
@@ -195,6 +197,11 @@ int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int
                    float* out, int out_mem);
 void encoder_release(vr_engine* e);
 int encoder_hidden(vr_engine* e);  // 0 when no encoder is loaded
+
+// ---- profile.hip: HIP-event timing of one launch (no-ops unless vr_profile(e, 1))
+void prof_begin(vr_engine* e, int kernel_class, double work);
+void prof_end(vr_engine* e);
+void prof_release(vr_engine* e);
 
 // ---- filter.hip
 // returns the device mask to use for this query (live[] when no filter is active)

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void sparse_scores_kernel(
 }
 
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
-                  const uint8_t* mask_dev) {
+                  const uint8_t* mask_dev, bool weights_given) {
   VR_CHECK(nnz >= 1 && nnz <= kMaxQueryTerms, "sparse query with %d terms (1..%d supported)", nnz,
            kMaxQueryTerms);
   VR_TRY(e->sp_scores.grow(e->cap_rows, 0, e->stream));
@@ -310,19 +310,25 @@ int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
   }
   VR_HIP(hipMemcpyAsync(e->q_ids.p, hid, sizeof(int32_t) * static_cast<size_t>(nnz),
                         hipMemcpyHostToDevice, e->stream));
-  VR_HIP(hipMemcpyAsync(e->q_w.p + kMaxQueryTerms, hval, sizeof(float) * static_cast<size_t>(nnz),
-                        hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(query_weights_kernel, dim3(1), dim3(kMaxQueryTerms), 0, e->stream, e->q_ids.p,
-                     e->q_w.p + kMaxQueryTerms, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
-                     static_cast<float>(e->n_sparse_points), e->q_w.p);
+  // weights_given: q_val already carries q_t * idf_t (sharded search computes idf from the
+  // all-reduced, global document frequencies); otherwise the engine's own statistics are used
+  VR_HIP(hipMemcpyAsync(e->q_w.p + (weights_given ? 0 : kMaxQueryTerms), hval,
+                        sizeof(float) * static_cast<size_t>(nnz), hipMemcpyHostToDevice, e->stream));
+  if (!weights_given)
+    hipLaunchKernelGGL(query_weights_kernel, dim3(1), dim3(kMaxQueryTerms), 0, e->stream, e->q_ids.p,
+                       e->q_w.p + kMaxQueryTerms, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
+                       static_cast<float>(e->n_sparse_points), e->q_w.p);
   VR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->sp_scores.p), 0xFF800000u,
-                           static_cast<size_t>(e->cap_rows), e->stream));
+                           static_cast<size_t>(e->n_rows), e->stream));
   if (e->n_slices_dev > 0) {
     int64_t blocks = (e->n_slices_dev + 3) / 4;
     if (blocks > 2048) blocks = 2048;
+    // algorithmic bytes: every stored id once (4 B), one mask byte and one score per row
+    prof_begin(e, VR_PROF_SPARSE_SCAN, 4.0 * static_cast<double>(e->sp_used) + 5.0 * static_cast<double>(e->n_rows));
     hipLaunchKernelGGL(sparse_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                        e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, e->q_ids.p,
                        e->q_w.p, nnz, mask_dev, e->sp_scores.p);
+    prof_end(e);
   }
   VR_HIP(hipGetLastError());
   return 0;

@@ -124,6 +124,22 @@ class Engine:
         if ptr != getattr(self, "_bound", 0):
             self.set_stream(ptr)
 
+    # ---- measurement ----------------------------------------------------------------------
+    PROF_GEMM, PROF_ATTENTION, PROF_DENSE_SCAN, PROF_SPARSE_SCAN = 0, 1, 2, 3
+
+    def profile(self, enable: bool) -> None:
+        """HIP-event timing of the engine's kernels on its own stream (vr_profile)."""
+        check(self._lib.vr_profile(self._h, int(enable)))
+
+    def profile_read(self, kernel_class: int) -> tuple[float, int, float]:
+        """-> (total milliseconds, launches, total algorithmic work: FLOP or bytes)"""
+        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        check(self._lib.vr_profile_read(self._h, kernel_class, C.byref(ms), C.byref(n), C.byref(w)))
+        return float(ms.value), int(n.value), float(w.value)
+
+    def idf(self, n_points: int, df: int) -> float:
+        return float(self._lib.vr_idf(int(n_points), int(df)))
+
     # ---- store ----------------------------------------------------------------------------
     def upsert(self, dense, sparse=None, folder_ids=None, index_folder_ids=None, created=None,
                modified=None) -> int:
@@ -277,14 +293,16 @@ class Engine:
         del keep
         return [(rows[i, : counts[i]].copy(), scores[i, : counts[i]].copy()) for i in range(nq)]
 
-    def search_sparse(self, q_idx, q_val, k: int, flt: SearchFilter | None = None):
+    def search_sparse(self, q_idx, q_val, k: int, flt: SearchFilter | None = None, weights_given: bool = False):
+        """weights_given: q_val already holds q_t * idf_t (sharded search with global statistics)."""
         qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
         rows = np.empty(k, np.int64)
         scores = np.empty(k, np.float32)
         c = C.c_int32()
         fp, keep = self._filter(flt)
-        check(self._lib.vr_search_sparse(self._h, _ptr(qi, C.c_int32), _ptr(qv, C.c_float), qi.shape[0], k, fp,
-                                         _ptr(rows, C.c_int64), _ptr(scores, C.c_float), C.byref(c)))
+        check(self._lib.vr_search_sparse(self._h, _ptr(qi, C.c_int32), _ptr(qv, C.c_float), qi.shape[0], k,
+                                         int(weights_given), fp, _ptr(rows, C.c_int64), _ptr(scores, C.c_float),
+                                         C.byref(c)))
         del keep
         return rows[: c.value].copy(), scores[: c.value].copy()
 
