@@ -133,6 +133,28 @@ def populate(torch, gen, dev, engine, rows, dim):
     return keep
 
 
+def pmc_traffic(kernel_prefix: str):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, see profiles/README.md), corrected
+    as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE reports half
+    the bytes of a wide coalesced read, so traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+    None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_fetch_write_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        summ = json.load(open(path))
+        n = f = w = 0.0
+        for name, row in summ.items():
+            if kernel_prefix in name:
+                n += row["launches"]
+                f += row["FETCH_SIZE_KB_avg"] * row["launches"]
+                w += row["WRITE_SIZE_KB_avg"] * row["launches"]
+        return None if n == 0 else round((2.0 * f + w) * 1024.0 / n)
+    except Exception:
+        return None
+
+
 def host_cores() -> int:
     """Cores this process may actually use: cgroup quota and affinity, not the machine's count
     (a 1-GPU box exposes 256 logical CPUs but schedules a share of them)."""
@@ -338,7 +360,8 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(gemm_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic("gemm_f32_kernel"),
+                "algorithmic_flop_per_launch": round(gemm_flop / max(gemm_n, 1)),
                 "launches": gemm_n,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "share_of_step_time": round(gemm_ms * 1e-3 / dt, 4),
@@ -350,7 +373,8 @@ def main():
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": round(scan_gbps / PEAK_HBM_GBPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic("dense_scores_kernel"),
+                "algorithmic_bytes_per_launch": round(scan_bytes / max(scan_n, 1)),
                 "launches": scan_n,
                 "avg_launch_ms": round(scan_ms / max(scan_n, 1), 4),
                 "sparse_scan_avg_ms": round(sp_ms / max(sp_n, 1), 4),
