@@ -143,6 +143,17 @@ int vr_bm25_tf(vr_engine* e, const int64_t* tok_off, const int32_t* tok_ids, int
                double k, double b, double avg_len,
                int32_t* out_cnt, int32_t* out_idx, double* out_val);
 
+/* Host-only text side of fastembed's Bm25 (no engine, no GPU): remove_non_alphanumeric,
+ * SimpleTokenizer, stop-word / length filter, Snowball English stemmer, abs(murmur3_x86_32)
+ * (SURVEY.md a6/a7 [EXT]). texts[i]: lens[i] bytes of UTF-8. out_off: n+1 offsets; out_ids: the
+ * hashed stems of every text in order, at most `cap` written; *out_needed: total count (call
+ * again with a larger buffer when it exceeds cap). The same stream serves documents
+ * (-> vr_bm25_tf) and queries (Bm25.query_embed = the set of these ids, all values 1.0). */
+int vr_bm25_tokenize(const char* const* texts, const int64_t* lens, int64_t n,
+                     int64_t* out_off, int32_t* out_ids, int64_t cap, int64_t* out_needed);
+/* Snowball English (Porter2) stem of one lower-case UTF-8 word; NUL-terminated into out. */
+int vr_porter2_stem(const char* word, int64_t len, char* out, int64_t cap);
+
 /* ---- fused indexing step: the three starred calls of IndexingService._index_file_standard
  * (src/voitta/services/indexing.py:527-530,560) — embed_texts, sparse embed_texts, store_chunks —
  * without leaving HBM: encode (vr_encode) -> BM25 tf (vr_bm25_tf) -> store (vr_upsert).
