@@ -1,0 +1,214 @@
+"""The three drop-in services end to end on the GPU, written like tests of the reference's own
+services would read: EmbeddingService / SparseEmbeddingService / VectorStoreService with the
+reference's signatures (src/voitta/services/{embedding,sparse_embedding,vector_store}.py), checked
+against the oracles. The checkpoint directory is synthetic (seeded weights + synthetic vocab.txt)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bert as obert
+from oracle import bm25 as obm
+from oracle import core as ocore
+from oracle import fusion as ofus
+
+pytestmark = pytest.mark.gpu
+
+WORDS = ("vector database index retrieval query embedding sparse dense hybrid fusion ranking chunk document folder "
+         "search engine kernel memory bandwidth wavefront matrix tile running jumped happily relational the of and "
+         "to in is it that was for on are as with they be at one have this from passage").split()
+
+
+def _vocab():
+    v = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("abcdefghijklmnopqrstuvwxyz0123456789.,!?:;'-")
+    v += ["##" + c for c in "abcdefghijklmnopqrstuvwxyz0123456789"]
+    v += WORDS + ["##ing", "##ed", "##s", "##ly", "##tion"]
+    return list(dict.fromkeys(v))
+
+
+def _checkpoint(tmp_path, name, pooling, seed=5):
+    d = tmp_path / name
+    (d / "1_Pooling").mkdir(parents=True)
+    (d / "2_Normalize").mkdir()
+    vocab = _vocab()
+    shape = obert.BertShape(2, 128, 4, 256, vocab=len(vocab), max_pos=64)
+    (d / "config.json").write_text(json.dumps({
+        "model_type": "bert", "hidden_size": shape.hidden, "num_hidden_layers": shape.layers,
+        "num_attention_heads": shape.heads, "intermediate_size": shape.intermediate, "vocab_size": shape.vocab,
+        "max_position_embeddings": shape.max_pos, "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu"}))
+    (d / "modules.json").write_text(json.dumps([
+        {"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+        {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"},
+        {"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"}]))
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": shape.hidden, "pooling_mode_cls_token": pooling == "cls",
+        "pooling_mode_mean_tokens": pooling == "mean"}))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 32, "do_lower_case": True}))
+    (d / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    w = obert.random_weights(shape, seed)
+    from safetensors.numpy import save_file
+
+    save_file({("bert." + k): v for k, v in w.items()}, str(d / "model.safetensors"))
+    return str(d), shape, w, vocab
+
+
+@pytest.fixture
+def native(monkeypatch, tmp_path, gpu):
+    from voitta_rag_amd import config, embedding, sparse_embedding, store_registry, vector_store
+
+    def setup(name="mini-model", pooling="mean"):
+        path, shape, w, vocab = _checkpoint(tmp_path, name, pooling)
+        monkeypatch.setenv("EMBEDDING_MODEL", path)
+        monkeypatch.setenv("EMBEDDING_DIMENSION", str(shape.hidden))
+        config.get_settings.cache_clear()
+        store_registry.reset()
+        embedding._embedding_service = None
+        sparse_embedding._sparse_embedding_service = None
+        vector_store._vector_store = None
+        return path, shape, w, vocab
+
+    yield setup
+    store_registry.reset()
+    config.get_settings.cache_clear()
+
+
+def _texts(rng, n):
+    return [" ".join(rng.choice(WORDS, size=int(rng.integers(1, 45)))) + rng.choice([".", "!", " running?", ""]) for _ in range(n)]
+
+
+def _oracle_embed(texts, shape, w, vocab, pooling):
+    from voitta_rag_amd.embedding import build_wordpiece_tokenizer
+
+    tok = build_wordpiece_tokenizer(vocab, True)
+    tok.enable_truncation(max_length=32)
+    seqs = [np.array(e.ids, np.int32) for e in tok.encode_batch(texts)]
+    assert max(len(s) for s in seqs) == 32  # truncation exercised
+    return obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
+
+
+@pytest.mark.parametrize("pooling", ["mean", "cls"])
+def test_embedding_service(native, pooling):
+    path, shape, w, vocab = native("mini-" + pooling, pooling)
+    from voitta_rag_amd.embedding import get_embedding_service
+
+    svc = get_embedding_service()
+    assert svc.dimension == shape.hidden and svc.embed_texts([]) == []
+    rng = np.random.default_rng(0)
+    texts = _texts(rng, 37) + ["Héllo, naïve wörld — running & jumped!", "x"]
+    got = np.array(svc.embed_texts(texts))
+    assert isinstance(svc.embed_texts(texts[:2]), list) and isinstance(svc.embed_texts(texts[:2])[0][0], float)
+    want = _oracle_embed(texts, shape, w, vocab, pooling)
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1)
+    assert np.max(np.abs(1 - cos)) < 1e-5
+    one = np.array(svc.embed_text(texts[3]))
+    assert one.shape == (shape.hidden,) and np.array_equal(one.astype(np.float32), got[3].astype(np.float32))
+    assert np.array_equal(np.array(svc.embed_query(texts[3])), one)  # no e5 in the name: no prefixes
+
+
+def test_e5_prefixes(native):
+    path, shape, w, vocab = native("my-e5-mini", "mean")
+    from voitta_rag_amd.embedding import get_embedding_service
+
+    svc = get_embedding_service()
+    t = "vector database"
+    want_p = _oracle_embed(["passage: " + t, " ".join(WORDS)], shape, w, vocab, "mean")[0]
+    want_q = _oracle_embed(["query: " + t, " ".join(WORDS)], shape, w, vocab, "mean")[0]
+    for got, want in ((svc.embed_text(t), want_p), (svc.embed_texts([t])[0], want_p), (svc.embed_query(t), want_q)):
+        assert abs(1 - float(np.dot(got, want))) < 1e-5
+
+
+def test_full_flow_like_indexing_service_and_mcp_search(native):
+    """indexing.py:527-560 then mcp_server.py:469-485, on the native singletons."""
+    path, shape, w, vocab = native()
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import ChunkMetadata, VectorStoreService, get_vector_store
+
+    rng = np.random.default_rng(1)
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    files = {"docs/a.md": ("docs", "docs"), "docs/sub/b.md": ("docs/sub", "docs"), "notes/c.txt": ("notes", "notes"),
+             "d.txt": ("", "")}
+    all_chunks, all_sparse, all_ids, all_meta = [], [], [], []
+    for fi, (fp, (folder, index_folder)) in enumerate(files.items()):
+        texts = _texts(rng, 20 + fi)
+        embeddings = emb.embed_texts(texts)
+        sparse_vectors = sp.embed_texts(texts)
+        metas = [ChunkMetadata(file_path=fp, folder_path=folder, index_folder=index_folder, file_name=os.path.basename(fp),
+                               chunk_index=i, total_chunks=len(texts), start_char=i * 10, end_char=i * 10 + 9,
+                               indexed_at="2026-01-01T00:00:00", source_modified_at=(1_700_000_000 + fi * 1000 + i) if fi != 2 else None,
+                               source_url="https://x/doc" if fi == 0 else None,
+                               source_page_count=7 if fi == 1 else None) for i in range(len(texts))]
+        ids = vs.store_chunks(list(zip(texts, embeddings, metas)), sparse_vectors=sparse_vectors)
+        assert len(ids) == len(set(ids)) == len(texts)
+        all_chunks += texts
+        all_sparse += sparse_vectors
+        all_ids += ids
+        all_meta += metas
+    n = len(all_chunks)
+    assert vs.get_collection_info()["points_count"] == n
+    assert vs.count_by_file("docs/a.md") == 20 and vs.count_by_file("nope") == 0
+    assert vs.count_chunks_for_files(["docs/a.md", "nope", "d.txt"]) == {"docs/a.md": 20, "d.txt": 23}
+    # "" -> prefix "" -> str.startswith("") is always true in the reference (vector_store.py:789,805): everything
+    assert vs.count_chunks_for_folder("docs") == (2, 41) and vs.count_chunks_for_folder("") == (4, 86)
+    assert vs.get_folder_stats_batch(["docs", "docs/sub", "zzz"]) == {"docs": (2, 41), "docs/sub": (1, 21), "zzz": (0, 0)}
+    assert vs.get_stored_page_count("docs/sub/b.md") == 7 and vs.get_stored_page_count("docs/a.md") is None
+    assert vs.get_file_paths_by_index_folder("docs") == {"docs/a.md", "docs/sub/b.md"}
+    assert [c.metadata.chunk_index for c in vs.get_chunks_by_range("docs/a.md", 3, 6)] == [3, 4, 5, 6]
+    assert len(vs.find_by_source_url("https://x/doc")) == 20
+    assert vs.get_file_chunk_counts("docs/") == {"docs/a.md": 20, "docs/sub/b.md": 21}
+
+    # the oracle's view of what is stored
+    stored = ocore.cosine_preprocess(np.array([emb.embed_texts([t])[0] for t in all_chunks[:3]], np.float32))
+    assert stored.shape[0] == 3  # (smoke: single-text embeds work while the store holds rows)
+    dense_all = np.array(emb.embed_texts(all_chunks), np.float32)
+    xh = ocore.cosine_preprocess(dense_all)
+    sp_rows = [(np.array(i, np.int32), np.array(v, np.float64).astype(np.float32)) for i, v in all_sparse]
+    folder_of = np.array([m.folder_path for m in all_meta])
+    live = np.ones(n, bool)
+
+    def check(query, limit, sparse_weight, mask, **kw):
+        qv = emb.embed_query(query)
+        sq = sp.embed_query(query)
+        got = VectorStoreService().search(qv, limit=limit, sparse_query=sq, sparse_weight=sparse_weight, **kw)
+        m8 = (mask & live).astype(np.uint8)
+        dsc = ocore.dense_scores(ocore.cosine_preprocess(np.array([qv], np.float32)), xh)[0]
+        if sq[0]:
+            dr, ds = ocore.topk(dsc, 3 * limit, m8)
+            ssc = ocore.sparse_scores([r if live[i] else None for i, r in enumerate(sp_rows)], sq[0], sq[1], live)
+            sr, ss = ocore.topk(ssc, 3 * limit, m8)
+            want = ofus.hybrid_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())), limit,
+                                    sparse_weight)
+            assert [c.id for c in got] == [all_ids[r] for r, _, _ in want]
+            assert [c.score for c in got] == [s for _, s, _ in want]
+        else:
+            dr, ds = ocore.topk(dsc, limit, m8)
+            assert [c.id for c in got] == [all_ids[r] for r in dr]
+            assert [c.score for c in got] == [float(str(np.float32(s))) for s in ds]
+        for c in got:
+            r = all_ids.index(c.id)
+            assert c.text == all_chunks[r] and c.metadata.file_path == all_meta[r].file_path
+        return got
+
+    everything = np.ones(n, bool)
+    check("vector database retrieval", 10, 0.1, everything)
+    check("the of and", 5, 0.1, everything)  # sparse query empty -> dense-only branch (:599-619)
+    check("hybrid fusion ranking", 7, 0.5, folder_of == "docs", folder_filter="docs")
+    check("kernel memory", 10, 0.1, np.isin(folder_of, ["docs/sub", "notes"]), include_folders=["docs/sub", "notes", "ghost"])
+    check("chunk document", 10, 0.1, ~np.isin(folder_of, ["docs"]), exclude_folders=["docs"], exclude_index_folders=["nothing"])
+    mod = np.array([m.source_modified_at if m.source_modified_at is not None else -1 for m in all_meta])
+    check("search engine", 10, 0.1, (mod >= 1_700_001_000), date_start=1_700_001_000)
+    assert VectorStoreService().search(emb.embed_query("x"), folder_filter="ghost") == []
+
+    # re-index one file: delete + store again (indexing.py:281-288)
+    assert vs.delete_by_file("docs/a.md") == 20 and vs.delete_by_file("docs/a.md") == 0
+    live[:20] = False
+    check("vector database retrieval", 10, 0.1, everything)
+    assert vs.delete_by_folder("notes") == 22
+    live[[i for i, m in enumerate(all_meta) if m.folder_path == "notes"]] = False
+    assert vs.delete_by_index_folder("docs") == 21
+    live[[i for i, m in enumerate(all_meta) if m.index_folder == "docs"]] = False
+    check("running happily", 10, 0.3, everything)
+    vs.set_file_acl("d.txt", ["a@b.c"])
+    assert all(c.metadata.allowed_users == ["a@b.c"] for c in vs.get_chunks_by_range("d.txt", 0, 99))
+    assert vs.get_collection_info()["points_count"] == 23

@@ -37,6 +37,7 @@ __global__ void filter_mask_kernel(const uint8_t* __restrict__ live,
 int filter_build_mask(vr_engine* e, const vr_filter* f, const uint8_t** mask_out) {
   *mask_out = e->live.p;
   if (!f) return 0;
+  VR_CHECK(f->struct_size == static_cast<int32_t>(sizeof(vr_filter)), "vr_filter size mismatch");
   const bool folder_active = f->n_must_folder_sets > 0 || f->n_not_folder > 0;
   const bool ifolder_active = f->n_not_index_folder > 0;
   const bool date_active = f->has_date_start || f->has_date_end;

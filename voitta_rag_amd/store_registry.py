@@ -1,0 +1,48 @@
+"""Process-wide engine + collection state. The reference keeps all state in the Qdrant server,
+so a fresh ``VectorStoreService()`` (api/routes/folders.py:137-143) sees everything; here the
+state lives in this registry, never in the service objects (SURVEY.md §8b "Threading")."""
+from __future__ import annotations
+
+import threading
+
+from .config import get_settings
+
+_lock = threading.Lock()
+_engine = None
+_collections: dict = {}
+
+
+def get_engine():
+    """The single Engine of this process (one process per GPU)."""
+    global _engine
+    with _lock:
+        if _engine is None:
+            from .engine import Engine
+
+            s = get_settings()
+            _engine = Engine(s.embedding_dimension, device=s.gpu, initial_rows=s.initial_rows)
+        return _engine
+
+
+def set_engine(engine) -> None:
+    """Tests and multi-GPU launchers install their own engine."""
+    global _engine
+    with _lock:
+        _engine = engine
+        _collections.clear()
+
+
+def collection(name: str, factory):
+    with _lock:
+        if name not in _collections:
+            _collections[name] = factory()
+        return _collections[name]
+
+
+def reset() -> None:
+    global _engine
+    with _lock:
+        if _engine is not None:
+            _engine.close()
+        _engine = None
+        _collections.clear()

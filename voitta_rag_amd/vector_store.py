@@ -1,0 +1,409 @@
+"""Drop-in for the reference's VectorStoreService (src/voitta/services/vector_store.py): same
+dataclasses, method names, argument meaning, return types and error behaviour. The Qdrant server
+behind ``self.client`` is replaced by the in-process engine: vectors, sparse rows and the numeric
+filter columns live in HBM; the payload (text + metadata), the UUID <-> row map and the
+folder-string dictionaries stay in this host table.
+
+Error convention kept from the reference: store/search/delete/set_file_acl raise; the count_* /
+get_* helpers swallow exceptions and return 0 / {} / [] / None (vector_store.py:727,773,812,865,
+894,975,1014)."""
+from __future__ import annotations
+
+import logging
+import threading
+import uuid
+from dataclasses import dataclass
+
+import numpy as np
+
+from .config import get_settings
+from .engine import VR_TS_ABSENT, SearchFilter
+from .sparse_embedding import SPARSE_VECTOR_NAME  # noqa: F401  (re-exported like the reference)
+from .store_registry import collection, get_engine
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class ChunkMetadata:
+    """Metadata for a stored chunk (vector_store.py:18-41)."""
+
+    file_path: str
+    folder_path: str
+    index_folder: str
+    file_name: str
+    chunk_index: int
+    total_chunks: int
+    start_char: int
+    end_char: int
+    indexed_at: str
+    start_page: int | None = None
+    end_page: int | None = None
+    source_page_count: int | None = None
+    source_created_at: int | None = None
+    source_modified_at: int | None = None
+    allowed_users: list[str] | None = None
+    source_url: str | None = None
+
+
+@dataclass
+class StoredChunk:
+    """A chunk stored in the vector database (vector_store.py:44-51)."""
+
+    id: str
+    text: str
+    metadata: ChunkMetadata
+    score: float | None = None
+
+
+class _Collection:
+    """Host half of one collection: payload rows and string dictionaries."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.ids: list[str | None] = []        # row -> point id (None once deleted)
+        self.payload: list[dict | None] = []   # row -> payload dict
+        self.row_of: dict[str, int] = {}
+        self.rows_by_file: dict[str, list[int]] = {}
+        self.folder_ids: dict[str, int] = {}
+        self.index_folder_ids: dict[str, int] = {}
+
+    def folder_id(self, name: str, create: bool) -> int:
+        if name not in self.folder_ids:
+            if not create:
+                return -1  # never stored: matches no row
+            self.folder_ids[name] = len(self.folder_ids)
+        return self.folder_ids[name]
+
+    def index_folder_id(self, name: str, create: bool) -> int:
+        if name not in self.index_folder_ids:
+            if not create:
+                return -1
+            self.index_folder_ids[name] = len(self.index_folder_ids)
+        return self.index_folder_ids[name]
+
+    def live_rows(self):
+        return (r for r, p in enumerate(self.payload) if p is not None)
+
+
+def _json_float(x) -> float:
+    """The reference reads scores from Qdrant's REST/JSON replies: an f32 printed with the shortest
+    round-tripping decimal, parsed by Python [EXT]."""
+    return float(str(np.float32(x)))
+
+
+class VectorStoreService:
+    """Service for storing and retrieving document chunks in the native engine."""
+
+    def __init__(self):
+        settings = get_settings()
+        self.collection_name = settings.qdrant_collection
+        self.dimension = settings.embedding_dimension
+        self._client = None
+        self._has_sparse: bool = False
+
+    # ---- the "client": engine + host table ------------------------------------------------------
+    @property
+    def client(self):
+        if self._client is None:
+            logger.info("Binding collection '%s' to the native engine", self.collection_name)
+            self._client = get_engine()
+            self._ensure_collection()
+        return self._client
+
+    def _ensure_collection(self) -> None:
+        collection(self.collection_name, _Collection)
+        self._has_sparse = True  # every collection is created with the "bm25" sparse vector (:95-99,114)
+
+    @property
+    def _col(self) -> _Collection:
+        self.client  # noqa: B018  (lazy bind)
+        return collection(self.collection_name, _Collection)
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _payload_of(text: str, metadata: ChunkMetadata) -> dict:
+        payload = {  # vector_store.py:259-288
+            "text": text,
+            "file_path": metadata.file_path,
+            "folder_path": metadata.folder_path,
+            "index_folder": metadata.index_folder,
+            "file_name": metadata.file_name,
+            "chunk_index": metadata.chunk_index,
+            "total_chunks": metadata.total_chunks,
+            "start_char": metadata.start_char,
+            "end_char": metadata.end_char,
+            "indexed_at": metadata.indexed_at,
+        }
+        for key in ("start_page", "end_page", "source_page_count", "source_created_at", "source_modified_at",
+                    "allowed_users", "source_url"):
+            value = getattr(metadata, key)
+            if value is not None:
+                payload[key] = value
+        return payload
+
+    @staticmethod
+    def _chunk_from(point_id: str, payload: dict, score) -> StoredChunk:
+        return StoredChunk(  # _result_to_chunk, vector_store.py:532-558
+            id=str(point_id),
+            text=payload["text"],
+            metadata=ChunkMetadata(
+                file_path=payload["file_path"],
+                folder_path=payload["folder_path"],
+                index_folder=payload.get("index_folder", payload["folder_path"]),
+                file_name=payload["file_name"],
+                chunk_index=payload["chunk_index"],
+                total_chunks=payload["total_chunks"],
+                start_char=payload["start_char"],
+                end_char=payload["end_char"],
+                indexed_at=payload["indexed_at"],
+                start_page=payload.get("start_page"),
+                end_page=payload.get("end_page"),
+                source_page_count=payload.get("source_page_count"),
+                source_created_at=payload.get("source_created_at"),
+                source_modified_at=payload.get("source_modified_at"),
+                allowed_users=payload.get("allowed_users"),
+                source_url=payload.get("source_url"),
+            ),
+            score=score,
+        )
+
+    def _delete_rows(self, rows: list[int]) -> int:
+        col = self._col
+        rows = [r for r in rows if col.payload[r] is not None]
+        if rows:
+            self.client.delete_rows(np.asarray(rows, np.int64))
+            for r in rows:
+                p = col.payload[r]
+                lst = col.rows_by_file.get(p["file_path"])
+                if lst is not None:
+                    lst.remove(r)
+                    if not lst:
+                        del col.rows_by_file[p["file_path"]]
+                col.row_of.pop(col.ids[r], None)
+                col.payload[r] = None
+                col.ids[r] = None
+        return len(rows)
+
+    # ---- store ------------------------------------------------------------------------------------
+    def store_chunks(self, chunks: list[tuple[str, list[float], ChunkMetadata]],
+                     sparse_vectors: list[tuple[list[int], list[float]]] | None = None,
+                     batch_size: int = 100) -> list[str]:
+        """Store chunks with their embeddings; returns the generated point ids (vector_store.py:233-317).
+        ``batch_size`` only bounded HTTP payloads in the reference; rows go to HBM in one append."""
+        if not chunks:
+            return []
+        col = self._col
+        n = len(chunks)
+        dense = np.asarray([c[1] for c in chunks], dtype=np.float32).reshape(n, self.dimension)
+        with col.lock:
+            folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
+            ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
+            created = np.array([VR_TS_ABSENT if c[2].source_created_at is None else int(c[2].source_created_at)
+                                for c in chunks], np.int64)
+            modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
+                                 for c in chunks], np.int64)
+            sparse = None
+            if sparse_vectors:
+                # a chunk beyond len(sparse_vectors) is stored dense-only (:291,299-300): empty row here
+                sparse = [sparse_vectors[i] if i < len(sparse_vectors) else ([], []) for i in range(n)]
+            first = self.client.upsert(dense, sparse=sparse, folder_ids=folder, index_folder_ids=ifolder,
+                                       created=created, modified=modified)
+            assert first == len(col.payload), "host table and engine rows diverged"
+            ids = []
+            for i, (text, _emb, metadata) in enumerate(chunks):
+                point_id = str(uuid.uuid4())  # :256
+                ids.append(point_id)
+                col.ids.append(point_id)
+                col.payload.append(self._payload_of(text, metadata))
+                col.row_of[point_id] = first + i
+                col.rows_by_file.setdefault(metadata.file_path, []).append(first + i)
+        logger.info(f"Stored {n} chunks in the native engine")
+        return ids
+
+    # ---- deletes / ACL ----------------------------------------------------------------------------
+    def delete_by_file(self, file_path: str) -> int:
+        col = self._col
+        with col.lock:
+            count = self._delete_rows(list(col.rows_by_file.get(file_path, [])))
+        if count > 0:
+            logger.info(f"Deleted {count} chunks for file: {file_path}")
+        return count
+
+    def delete_by_folder(self, folder_path: str) -> int:
+        col = self._col
+        with col.lock:
+            count = self._delete_rows([r for r in col.live_rows() if col.payload[r]["folder_path"] == folder_path])
+        if count > 0:
+            logger.info(f"Deleted {count} chunks for folder: {folder_path}")
+        return count
+
+    def delete_by_index_folder(self, index_folder: str) -> int:
+        col = self._col
+        with col.lock:
+            count = self._delete_rows([r for r in col.live_rows() if col.payload[r].get("index_folder") == index_folder])
+        if count > 0:
+            logger.info(f"Deleted {count} chunks for index_folder: {index_folder}")
+        return count
+
+    def set_file_acl(self, file_path: str, allowed_users: list[str]) -> None:
+        col = self._col
+        with col.lock:
+            for r in col.rows_by_file.get(file_path, []):
+                col.payload[r]["allowed_users"] = allowed_users
+
+    # ---- search -----------------------------------------------------------------------------------
+    def _build_filter(self, folder_filter: str | None = None, include_folders: list[str] | None = None,
+                      exclude_folders: list[str] | None = None, exclude_index_folders: list[str] | None = None,
+                      date_start: int | None = None, date_end: int | None = None,
+                      date_field: str | None = None) -> SearchFilter | None:
+        """Integer form of the Qdrant filter the reference builds (vector_store.py:462-530)."""
+        col = self._col
+        flt = SearchFilter()
+        if folder_filter:
+            flt.folder_filter = col.folder_id(folder_filter, False)
+        if include_folders:
+            flt.include_folders = [col.folder_id(f, False) for f in include_folders]
+        if exclude_folders:
+            flt.exclude_folders = [i for i in (col.folder_id(f, False) for f in exclude_folders) if i >= 0]
+        if exclude_index_folders:
+            flt.exclude_index_folders = [i for i in (col.index_folder_id(f, False) for f in exclude_index_folders) if i >= 0]
+        if date_start is not None or date_end is not None:
+            flt.date_start, flt.date_end, flt.date_field = date_start, date_end, date_field
+        return None if flt.is_empty() else flt
+
+    def search(self, query_embedding: list[float], limit: int = 10, folder_filter: str | None = None,
+               include_folders: list[str] | None = None, exclude_folders: list[str] | None = None,
+               exclude_index_folders: list[str] | None = None,
+               sparse_query: tuple[list[int], list[float]] | None = None, sparse_weight: float = 0.1,
+               date_start: int | None = None, date_end: int | None = None,
+               date_field: str | None = None) -> list[StoredChunk]:
+        """Dense or hybrid retrieval with the reference's branch selection (vector_store.py:560-619)."""
+        col = self._col
+        q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
+        with col.lock:
+            search_filter = self._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
+                                               date_start=date_start, date_end=date_end, date_field=date_field)
+            if sparse_query and self._has_sparse:
+                indices, values = sparse_query
+                if indices:
+                    rows, scores, _ = self.client.search_hybrid(q, indices, values, limit, sparse_weight,
+                                                                flt=search_filter)
+                    return [self._chunk_from(col.ids[r], col.payload[r], float(s)) for r, s in zip(rows, scores)]
+            rows, scores = self.client.search_dense(q[None, :], limit, search_filter)[0]
+            return [self._chunk_from(col.ids[r], col.payload[r], _json_float(s)) for r, s in zip(rows, scores)]
+
+    # ---- read helpers (payload only) ---------------------------------------------------------------
+    def find_by_source_url(self, source_url: str) -> list[StoredChunk]:
+        col = self._col
+        with col.lock:
+            chunks = [self._chunk_from(col.ids[r], col.payload[r], None) for r in col.live_rows()
+                      if col.payload[r].get("source_url") == source_url]
+        chunks.sort(key=lambda c: c.metadata.chunk_index)
+        return chunks
+
+    def get_file_paths_by_index_folder(self, index_folder: str) -> set[str]:
+        col = self._col
+        with col.lock:
+            return {col.payload[r]["file_path"] for r in col.live_rows() if col.payload[r].get("index_folder") == index_folder}
+
+    def get_collection_info(self) -> dict:
+        try:
+            n_rows, n_live = self.client.count()
+            return {"name": self.collection_name, "vectors_count": n_live, "points_count": n_live, "status": "green"}
+        except Exception as e:
+            return {"error": str(e)}
+
+    def count_by_file(self, file_path: str) -> int:
+        try:
+            col = self._col
+            with col.lock:
+                return len(col.rows_by_file.get(file_path, []))
+        except Exception:
+            return 0
+
+    def count_chunks_for_files(self, file_paths: list[str]) -> dict[str, int]:
+        if not file_paths:
+            return {}
+        try:
+            col = self._col
+            with col.lock:
+                return {fp: len(col.rows_by_file[fp]) for fp in dict.fromkeys(file_paths) if col.rows_by_file.get(fp)}
+        except Exception as e:
+            logger.error(f"Error counting chunks for files: {e}")
+            return {}
+
+    @staticmethod
+    def _in_folder(file_path: str, prefix: str) -> bool:
+        return file_path.startswith(prefix) or (not prefix and "/" not in file_path)  # vector_store.py:805
+
+    def count_chunks_for_folder(self, folder_path: str) -> tuple[int, int]:
+        try:
+            prefix = folder_path + "/" if folder_path else ""
+            col = self._col
+            with col.lock:
+                counts = {fp: len(rows) for fp, rows in col.rows_by_file.items() if self._in_folder(fp, prefix)}
+            return len(counts), sum(counts.values())
+        except Exception as e:
+            logger.error(f"Error counting chunks for folder {folder_path}: {e}")
+            return 0, 0
+
+    def get_folder_stats_batch(self, folder_paths: list[str]) -> dict[str, tuple[int, int]]:
+        if not folder_paths:
+            return {}
+        try:
+            col = self._col
+            out = {}
+            with col.lock:
+                for fp in folder_paths:
+                    prefix = fp + "/" if fp else ""
+                    counts = [len(rows) for f, rows in col.rows_by_file.items() if self._in_folder(f, prefix)]
+                    out[fp] = (len(counts), sum(counts))
+            return out
+        except Exception as e:
+            logger.error(f"Error getting folder stats batch: {e}")
+            return {fp: (0, 0) for fp in folder_paths}
+
+    def get_stored_page_count(self, file_path: str) -> int | None:
+        try:
+            col = self._col
+            with col.lock:
+                rows = col.rows_by_file.get(file_path, [])
+                if rows and col.payload[rows[0]].get("source_page_count"):
+                    return col.payload[rows[0]]["source_page_count"]
+            return None
+        except Exception as e:
+            logger.error(f"Error getting stored page count for {file_path}: {e}")
+            return None
+
+    def get_chunks_by_range(self, file_path: str, first_chunk: int, last_chunk: int) -> list[StoredChunk]:
+        try:
+            col = self._col
+            with col.lock:
+                chunks = [self._chunk_from(col.ids[r], col.payload[r], None) for r in col.rows_by_file.get(file_path, [])
+                          if first_chunk <= col.payload[r]["chunk_index"] <= last_chunk]
+            chunks.sort(key=lambda c: c.metadata.chunk_index)
+            return chunks
+        except Exception as e:
+            logger.error(f"Error getting chunks by range for {file_path}: {e}")
+            return []
+
+    def get_file_chunk_counts(self, folder_prefix: str = "") -> dict[str, int]:
+        try:
+            col = self._col
+            with col.lock:
+                return {fp: len(rows) for fp, rows in col.rows_by_file.items()
+                        if not folder_prefix or fp.startswith(folder_prefix)}
+        except Exception as e:
+            logger.error(f"Error getting file chunk counts: {e}")
+            return {}
+
+
+_vector_store: VectorStoreService | None = None
+
+
+def get_vector_store() -> VectorStoreService:
+    global _vector_store
+    if _vector_store is None:
+        _vector_store = VectorStoreService()
+    return _vector_store
