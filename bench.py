@@ -53,6 +53,9 @@ def parse():
     p.add_argument("--queries", type=int, default=1000)
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="rehearsal only: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     return p.parse_args()
 
 
@@ -228,11 +231,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from voitta_rag_amd import Engine
     from voitta_rag_amd import encoder as enc
@@ -269,7 +278,7 @@ def main():
     attn_ms, attn_n, attn_flop = engine.profile_read(Engine.PROF_ATTENTION)
     engine.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     chunks_per_s = world * args.steps * args.batch / dt
@@ -304,7 +313,7 @@ def main():
     engine.profile(False)
     p50, p99 = float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3)
     if world > 1:
-        t = torch.tensor([p50, p99], dtype=torch.float64, device=dev)
+        t = torch.tensor([p50, p99], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         p50, p99 = float(t[0]), float(t[1])
     dense_only = [engine.search_dense(qs_host[20 + i: 21 + i], 10) for i in range(min(50, args.queries))]
