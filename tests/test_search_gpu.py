@@ -53,7 +53,7 @@ def test_store_and_dense_search_bit_exact(gpu, dim, n):
     q = rng.standard_normal((21, dim)).astype(np.float32)
     q[3] = x[17]  # exact duplicate of a stored row
     want_scores = ocore.dense_scores(ocore.cosine_preprocess(q), want_x)
-    for k in (1, 10, 30):
+    for k in (1, 10, 30, 64, 70):  # <= 64: fused scan+select; above: score array + select kernels
         got = e.search_dense(q, k)
         for i in range(q.shape[0]):
             wr, ws = ocore.topk(want_scores[i], k)
@@ -147,7 +147,7 @@ def test_sparse_and_hybrid_bit_exact(gpu):
                 qi[0] = 5  # a token no document has
             qv = np.ones(m, np.float32)
             want = ocore.sparse_scores(sp, qi, qv, live)
-            for k in (10, 30):
+            for k in (10, 30, 100):
                 wr, ws = ocore.topk(want, k, live.astype(np.uint8))
                 gr, gs = e.search_sparse(qi, qv, k)
                 assert np.array_equal(gr, wr), (round_, trial, k)

@@ -69,33 +69,44 @@ static int64_t decode_keys(const uint64_t* keys, int k, int64_t* rows, float* sc
   return n;
 }
 
-constexpr size_t kPinnedBytes = 1 << 20;
-constexpr size_t kPinnedResultOff = 8192;
-
 static int check_engine(vr_engine* e) {
   VR_CHECK(e != nullptr, "null engine");
   VR_HIP(hipSetDevice(e->device));
   return 0;
 }
 
-static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k,
-                              const uint8_t* mask, uint64_t* host_keys /* pinned, nq*k */) {
+// A host query block goes into the pinned scratch and is read from there by query_image_kernel:
+// no hipMemcpy on the latency path. Returns the pointer the kernels should read.
+static const float* stage_query(vr_engine* e, const float* q, int nq, int mem) {
+  if (mem == VR_MEM_DEVICE) return q;
+  memcpy(pin_host<float>(e, kPinQuery), q, sizeof(float) * static_cast<size_t>(nq) * e->dim);
+  return pin_dev<float>(e, kPinQuery);
+}
+
+// nq*k keys land in the pinned result area at kPinDenseKeys (readable after a stream sync)
+static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t* mask) {
   VR_TRY(dense_make_query_image(e, q_dev, nq));
-  VR_TRY(dense_scores(e, nq, mask));
+  // one or a few queries: scan and selection in one pass, results straight to pinned. A full
+  // 16-query block offers 16x the candidates per tile; there the score array + select kernels win.
+  if (k <= kFusedMaxK && nq <= 4)
+    return dense_scan_topk(e, nq, k, mask, pin_dev<uint64_t>(e, kPinDenseKeys));
   const uint64_t* keys = nullptr;
+  VR_TRY(dense_scores(e, nq, mask));
   VR_TRY(topk_select(e, e->scores.p, e->cap_rows, e->n_rows, nq, k, &keys));
-  VR_HIP(hipMemcpyAsync(host_keys, keys, sizeof(uint64_t) * static_cast<size_t>(nq) * k,
+  VR_HIP(hipMemcpyAsync(pin_host<uint64_t>(e, kPinDenseKeys), keys, sizeof(uint64_t) * static_cast<size_t>(nq) * k,
                         hipMemcpyDeviceToHost, e->stream));
   return 0;
 }
 
+// k keys land at kPinSparseKeys
 static int search_sparse_block(vr_engine* e, const int32_t* q_idx, const float* q_val, int nnz, int k,
-                               const uint8_t* mask, bool weights_given,
-                               uint64_t* host_keys /* pinned, k */) {
-  VR_TRY(sparse_scores(e, q_idx, q_val, nnz, mask, weights_given));
+                               const uint8_t* mask, bool weights_given) {
+  if (k <= kFusedMaxK)
+    return sparse_scan_topk(e, q_idx, q_val, nnz, k, mask, weights_given, pin_dev<uint64_t>(e, kPinSparseKeys));
   const uint64_t* keys = nullptr;
+  VR_TRY(sparse_scores(e, q_idx, q_val, nnz, mask, weights_given));
   VR_TRY(topk_select(e, e->sp_scores.p, e->cap_rows, e->n_rows, 1, k, &keys));
-  VR_HIP(hipMemcpyAsync(host_keys, keys, sizeof(uint64_t) * static_cast<size_t>(k),
+  VR_HIP(hipMemcpyAsync(pin_host<uint64_t>(e, kPinSparseKeys), keys, sizeof(uint64_t) * static_cast<size_t>(k),
                         hipMemcpyDeviceToHost, e->stream));
   return 0;
 }
@@ -139,8 +150,10 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
     return -1;
   }
   e->stream = e->own_stream;
-  if (hipHostMalloc(&e->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
-    set_error("hipHostMalloc failed");
+  if (hipHostMalloc(&e->pinned, kPinnedBytes, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0) != hipSuccess) {
+    set_error("hipHostMalloc (mapped) failed");
+    if (e->pinned) (void)hipHostFree(e->pinned);
     (void)hipStreamDestroy(e->own_stream);
     delete e;
     return -1;
@@ -518,17 +531,11 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
   }
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
-  uint64_t* host_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
+  const uint64_t* host_keys = pin_host<uint64_t>(e, kPinDenseKeys);
   for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
     const int nb = std::min(kQueryBlock, nq - q0);
-    const float* q_dev = q + static_cast<int64_t>(q0) * e->dim;
-    if (mem == VR_MEM_HOST) {
-      VR_TRY(e->stage_dense.grow(static_cast<int64_t>(kQueryBlock) * e->dim, 0, e->stream));
-      VR_HIP(hipMemcpyAsync(e->stage_dense.p, q_dev, sizeof(float) * static_cast<size_t>(nb) * e->dim,
-                            hipMemcpyHostToDevice, e->stream));
-      q_dev = e->stage_dense.p;
-    }
-    VR_TRY(search_dense_block(e, q_dev, nb, k, mask, host_keys));
+    const float* q_dev = stage_query(e, q + static_cast<int64_t>(q0) * e->dim, nb, mem);
+    VR_TRY(search_dense_block(e, q_dev, nb, k, mask));
     VR_HIP(hipStreamSynchronize(e->stream));
     for (int i = 0; i < nb; ++i) {
       int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k,
@@ -556,8 +563,8 @@ int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int
   VR_CHECK(q_idx && q_val, "null sparse query");
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
-  uint64_t* host_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
-  VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given != 0, host_keys));
+  const uint64_t* host_keys = pin_host<uint64_t>(e, kPinSparseKeys);
+  VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given != 0));
   VR_HIP(hipStreamSynchronize(e->stream));
   *count = static_cast<int32_t>(decode_keys(host_keys, k, rows, scores));
   return 0;
@@ -578,20 +585,13 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   const int k = limit * 3;  // prefetch_limit, vector_store.py:636
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
-  uint64_t* dense_keys = reinterpret_cast<uint64_t*>(static_cast<char*>(e->pinned) + kPinnedResultOff);
-  uint64_t* sparse_keys = dense_keys + kMaxK;
-  const float* q_dev = q;
-  if (mem == VR_MEM_HOST) {
-    VR_TRY(e->stage_dense.grow(static_cast<int64_t>(kQueryBlock) * e->dim, 0, e->stream));
-    VR_HIP(hipMemcpyAsync(e->stage_dense.p, q, sizeof(float) * static_cast<size_t>(e->dim),
-                          hipMemcpyHostToDevice, e->stream));
-    q_dev = e->stage_dense.p;
-  }
-  VR_TRY(search_dense_block(e, q_dev, 1, k, mask, dense_keys));
+  const uint64_t* dense_keys = pin_host<uint64_t>(e, kPinDenseKeys);
+  const uint64_t* sparse_keys = pin_host<uint64_t>(e, kPinSparseKeys);
+  VR_TRY(search_dense_block(e, stage_query(e, q, 1, mem), 1, k, mask));
   const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
   if (have_sparse) {
     VR_CHECK(q_idx && q_val, "null sparse query");
-    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, false, sparse_keys));
+    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, false));
   }
   VR_HIP(hipStreamSynchronize(e->stream));
   int64_t d_rows[kMaxK], s_rows[kMaxK];

@@ -86,6 +86,18 @@ constexpr int kTileK = 16;         // k elements per 1-KiB tile block
 constexpr int kTopkSeg = 4096;     // keys per block in the first select level
 constexpr int kMaxK = 256;         // largest top-k a search may ask for
 constexpr int kQueryBlock = 16;    // queries per dense pass (MFMA N)
+constexpr int kScanBlocks = 512;   // grid of the fused scan+select kernels: 2 blocks per CU, and
+                                   // 512 candidate lists per query for merge_lists_kernel
+constexpr int kFusedMaxK = 64;     // fused selection keeps lists of 64 (one entry per lane)
+constexpr int kMaxQueryTerms = 256;  // distinct terms of one sparse query
+
+// layout of the pinned scratch
+constexpr size_t kPinSparseIds = 0;            // int32[kMaxQueryTerms]
+constexpr size_t kPinSparseVals = 1024;        // float[kMaxQueryTerms]
+constexpr size_t kPinQuery = 8192;             // float[16][dim <= 1024]
+constexpr size_t kPinDenseKeys = 128 * 1024;   // uint64[16][kMaxK]
+constexpr size_t kPinSparseKeys = 192 * 1024;  // uint64[kMaxK]
+constexpr size_t kPinnedBytes = 1 << 20;
 
 }  // namespace vr
 
@@ -154,7 +166,11 @@ struct vr_engine {
   vr::DevArray<uint64_t> cand_b;
   vr::DevArray<int32_t> q_ids;
   vr::DevArray<float> q_w;
-  void* pinned = nullptr;  // host pinned scratch for small D2H results
+  // Pinned, device-mapped host scratch (1 MiB). Query inputs are written here by the host and
+  // read by the kernels straight over PCIe, results are written here by the last kernel of a
+  // search: the latency path of a query has no hipMemcpy at all.
+  void* pinned = nullptr;      // host address
+  void* pinned_dev = nullptr;  // the same memory as the device sees it
   size_t pinned_bytes = 0;
 
   void* encoder = nullptr;   // vr::Encoder (encoder.hip)
@@ -163,6 +179,15 @@ struct vr_engine {
 
 
 namespace vr {
+
+template <class T>
+inline T* pin_host(vr_engine* e, size_t off) {
+  return reinterpret_cast<T*>(static_cast<char*>(e->pinned) + off);
+}
+template <class T>
+inline T* pin_dev(vr_engine* e, size_t off) {
+  return reinterpret_cast<T*>(static_cast<char*>(e->pinned_dev) + off);
+}
 
 // ---- dense.hip
 int dense_store_rows(vr_engine* e, const float* x_dev, int64_t n, int64_t first_row);
@@ -175,6 +200,14 @@ int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out
 // query are left in *out_keys (device, [nq][k]).
 int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, int nq, int k,
                 const uint64_t** out_keys);
+// cand: [nq][n_lists][64] keys, every list sorted descending and zero padded (written by the
+// fused scan kernels); writes the k best of every query to out ([nq][k], descending; device-
+// visible memory, normally the pinned result area so that no copy follows).
+int topk_merge_lists(vr_engine* e, const uint64_t* cand, int n_lists, int nq, int k, uint64_t* out);
+// fused scan + selection, k <= kFusedMaxK; results to out_keys_dev as above
+int dense_scan_topk(vr_engine* e, int nq, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev);
+int sparse_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, int k,
+                     const uint8_t* mask_dev, bool weights_given, uint64_t* out_keys_dev);
 
 // ---- sparse.hip
 // rows of the batch live at idx/val[begin[r] .. +count); count = cnt_dev[r] or begin[r+1]-begin[r]

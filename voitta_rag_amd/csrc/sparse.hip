@@ -17,6 +17,7 @@
 // the table content does not depend on arrival order).
 
 #include "engine_internal.h"
+#include "topk_device.h"
 
 #include <algorithm>
 
@@ -209,53 +210,63 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
 
 // ---- query ------------------------------------------------------------------------------------
 
-constexpr int kQHash = 1024;  // LDS hash slots for the query terms
-constexpr int kMaxQueryTerms = 256;
+constexpr int kQHash = 1024;   // LDS hash slots for the query terms
+constexpr int kSparseWaves = 8;  // 512-thread blocks, as the dense scan
 
-// q_w[t] = q_val[t] * idf(t)
-__global__ void query_weights_kernel(const int32_t* __restrict__ q_idx,
-                                     const float* __restrict__ q_val, int nnz,
-                                     const int32_t* __restrict__ keys,
-                                     const int32_t* __restrict__ cnt, int64_t cap, float n_points,
-                                     float* __restrict__ q_w) {
-  int t = threadIdx.x;
-  if (t >= nnz) return;
-  float df = static_cast<float>(cap ? df_get(keys, cnt, cap, q_idx[t]) : 0);
-  float num = __fadd_rn(__fadd_rn(n_points, -df), 0.5f);
-  float den = __fadd_rn(df, 0.5f);
-  float arg = __fadd_rn(1.0f, __fdiv_rn(num, den));
-  // ln in f64, rounded once to f32. The empty asm hides that `a` is a widened float: otherwise
-  // LLVM shrinks (float)log((double)x) to logf(x), whose last bit differs from the host's.
-  double a = static_cast<double>(arg);
-  asm volatile("" : "+v"(a));
-  float idf = static_cast<float>(log(a));
-  q_w[t] = __fmul_rn(q_val[t], idf);
-}
-
-__global__ __launch_bounds__(256) void sparse_scores_kernel(
+// One kernel per sparse query. Prologue (every block, redundantly): read the <=256 sorted query
+// terms straight from the pinned host scratch, weight them — q_t * idf_t with idf from the
+// document-frequency table, or as given — and build an LDS hash. Body: SELL-64 scan, one row per
+// lane, ascending-id accumulation. FUSED keeps the k best (score, row) keys per wave
+// (topk_device.h) and writes one 64-entry list per block for merge_lists_kernel; otherwise a score
+// per row is written (-inf = shares no term / filtered).
+template <bool FUSED>
+__global__ __launch_bounds__(kSparseWaves * 64) void sparse_scores_kernel(
     const SliceDesc* __restrict__ slices, int64_t n_slices, const int32_t* __restrict__ sidx,
-    const float* __restrict__ sval, const int32_t* __restrict__ q_idx,
-    const float* __restrict__ q_w, int nnz, const uint8_t* __restrict__ mask,
-    float* __restrict__ scores) {
+    const float* __restrict__ sval, const int32_t* __restrict__ q_idx, const float* __restrict__ q_val,
+    int nnz, int weights_given, const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt,
+    int64_t df_cap, float n_points, const uint8_t* __restrict__ mask, float* __restrict__ scores, int k,
+    uint64_t* __restrict__ cand) {
   __shared__ int32_t hk[kQHash];
   __shared__ float hv[kQHash];
-  for (int i = threadIdx.x; i < kQHash; i += 256) hk[i] = -1;
+  __shared__ int32_t t_id[kMaxQueryTerms];
+  __shared__ float t_w[kMaxQueryTerms];
+  __shared__ uint64_t lists[kSparseWaves * kListLen];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t* list = lists + wave * kListLen;
+  lists[threadIdx.x] = 0ull;
+  for (int i = threadIdx.x; i < kQHash; i += kSparseWaves * 64) hk[i] = -1;
+  if (static_cast<int>(threadIdx.x) < nnz) {
+    const int32_t id = q_idx[threadIdx.x];
+    float w = q_val[threadIdx.x];
+    if (!weights_given) {
+      const float df = static_cast<float>(df_cap ? df_get(df_keys, df_cnt, df_cap, id) : 0);
+      const float num = __fadd_rn(__fadd_rn(n_points, -df), 0.5f);
+      const float den = __fadd_rn(df, 0.5f);
+      const float arg = __fadd_rn(1.0f, __fdiv_rn(num, den));
+      // ln in f64, rounded once to f32. The empty asm hides that `a` is a widened float: otherwise
+      // LLVM shrinks (float)log((double)x) to logf(x), whose last bit differs from the host's.
+      double a = static_cast<double>(arg);
+      asm volatile("" : "+v"(a));
+      w = __fmul_rn(w, static_cast<float>(log(a)));
+    }
+    t_id[threadIdx.x] = id;
+    t_w[threadIdx.x] = w;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {  // <= 256 terms; serial insert keeps the table deterministic
     for (int t = 0; t < nnz; ++t) {
-      int32_t id = q_idx[t];
+      const int32_t id = t_id[t];
       uint32_t h = df_hash(id) & (kQHash - 1);
       while (hk[h] != -1 && hk[h] != id) h = (h + 1) & (kQHash - 1);
       hk[h] = id;
-      hv[h] = q_w[t];
+      hv[h] = t_w[t];
     }
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
-  const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * 4;
-  for (int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); s < n_slices;
-       s += wave_stride) {
+  const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kSparseWaves;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * kSparseWaves + wave; s < n_slices; s += wave_stride) {
     const SliceDesc d = slices[s];
     float acc = 0.0f;
     bool hit = false;
@@ -280,20 +291,34 @@ __global__ __launch_bounds__(256) void sparse_scores_kernel(
         }
       }
     }
-    if (lane < d.nrows) {
-      int64_t row = d.row_base + lane;
-      scores[row] = (hit && mask[row]) ? acc : -__builtin_inff();
+    const bool in_slice = lane < d.nrows;
+    const int64_t row = d.row_base + lane;
+    const bool ok = in_slice && hit && mask[in_slice ? row : 0];
+    if (FUSED) {
+      wave_offer(list, k, ok ? topk_make_key(acc, row) : 0ull, 0, ok, lane);
+    } else if (in_slice) {
+      scores[row] = ok ? acc : -__builtin_inff();
+    }
+  }
+  if (FUSED) {  // fold the block's lists into one: cand[block][64], descending, zero padded
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < kSparseWaves; ++w)
+        for (int i = 0; i < k; ++i) {
+          const uint64_t key = lists[w * kListLen + i];
+          if (key == 0) break;
+          wave_list_insert(list, k, key, lane);
+        }
+      cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
     }
   }
 }
 
-int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
-                  const uint8_t* mask_dev, bool weights_given) {
+// fused_k == 0: scores of every row into e->sp_scores; fused_k > 0: top fused_k keys to out_keys_dev
+static int sparse_run(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
+                      const uint8_t* mask_dev, bool weights_given, int fused_k, uint64_t* out_keys_dev) {
   VR_CHECK(nnz >= 1 && nnz <= kMaxQueryTerms, "sparse query with %d terms (1..%d supported)", nnz,
            kMaxQueryTerms);
-  VR_TRY(e->sp_scores.grow(e->cap_rows, 0, e->stream));
-  VR_TRY(e->q_ids.grow(kMaxQueryTerms, 0, e->stream));
-  VR_TRY(e->q_w.grow(2 * kMaxQueryTerms, 0, e->stream));
   // ascending token id, duplicates merged by keeping the first (Qdrant sorts sparse vectors by
   // index on ingestion [EXT]); the hash lookup itself is order independent.
   std::vector<std::pair<int32_t, float>> q(static_cast<size_t>(nnz));
@@ -302,36 +327,56 @@ int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
   q.erase(std::unique(q.begin(), q.end(), [](const auto& a, const auto& b) { return a.first == b.first; }),
           q.end());
   nnz = static_cast<int>(q.size());
-  int32_t* hid = static_cast<int32_t*>(e->pinned);
-  float* hval = reinterpret_cast<float*>(hid + kMaxQueryTerms);
+  // the kernel reads the terms from the pinned scratch over PCIe: no copy, no extra launch
+  int32_t* hid = pin_host<int32_t>(e, kPinSparseIds);
+  float* hval = pin_host<float>(e, kPinSparseVals);
   for (int i = 0; i < nnz; ++i) {
     hid[i] = q[static_cast<size_t>(i)].first;
     hval[i] = q[static_cast<size_t>(i)].second;
   }
-  VR_HIP(hipMemcpyAsync(e->q_ids.p, hid, sizeof(int32_t) * static_cast<size_t>(nnz),
-                        hipMemcpyHostToDevice, e->stream));
-  // weights_given: q_val already carries q_t * idf_t (sharded search computes idf from the
-  // all-reduced, global document frequencies); otherwise the engine's own statistics are used
-  VR_HIP(hipMemcpyAsync(e->q_w.p + (weights_given ? 0 : kMaxQueryTerms), hval,
-                        sizeof(float) * static_cast<size_t>(nnz), hipMemcpyHostToDevice, e->stream));
-  if (!weights_given)
-    hipLaunchKernelGGL(query_weights_kernel, dim3(1), dim3(kMaxQueryTerms), 0, e->stream, e->q_ids.p,
-                       e->q_w.p + kMaxQueryTerms, nnz, e->df_keys.p, e->df_cnt.p, e->df_cap,
-                       static_cast<float>(e->n_sparse_points), e->q_w.p);
+  const int32_t* did = pin_dev<int32_t>(e, kPinSparseIds);
+  const float* dval = pin_dev<float>(e, kPinSparseVals);
+  const float n_points = static_cast<float>(e->n_sparse_points);
+  if (fused_k) {
+    int64_t blocks = std::min<int64_t>((e->n_slices_dev + kSparseWaves - 1) / kSparseWaves, kScanBlocks);
+    if (blocks < 1) blocks = 1;
+    VR_TRY(e->cand_a.grow(blocks * kListLen, 0, e->stream));
+    // algorithmic bytes: every stored id once (4 B) and one mask byte per row
+    prof_begin(e, VR_PROF_SPARSE_SCAN, 4.0 * static_cast<double>(e->sp_used) + static_cast<double>(e->n_rows));
+    hipLaunchKernelGGL((sparse_scores_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kSparseWaves * 64),
+                       0, e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, did, dval, nnz,
+                       weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev,
+                       static_cast<float*>(nullptr), fused_k, e->cand_a.p);
+    prof_end(e);
+    VR_HIP(hipGetLastError());
+    return topk_merge_lists(e, e->cand_a.p, static_cast<int>(blocks), 1, fused_k, out_keys_dev);
+  }
+  VR_TRY(e->sp_scores.grow(e->cap_rows, 0, e->stream));
   VR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->sp_scores.p), 0xFF800000u,
                            static_cast<size_t>(e->n_rows), e->stream));
   if (e->n_slices_dev > 0) {
-    int64_t blocks = (e->n_slices_dev + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = std::min<int64_t>((e->n_slices_dev + kSparseWaves - 1) / kSparseWaves, 1024);
     // algorithmic bytes: every stored id once (4 B), one mask byte and one score per row
     prof_begin(e, VR_PROF_SPARSE_SCAN, 4.0 * static_cast<double>(e->sp_used) + 5.0 * static_cast<double>(e->n_rows));
-    hipLaunchKernelGGL(sparse_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                       e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, e->q_ids.p,
-                       e->q_w.p, nnz, mask_dev, e->sp_scores.p);
+    hipLaunchKernelGGL((sparse_scores_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(kSparseWaves * 64),
+                       0, e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, did, dval, nnz,
+                       weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev,
+                       e->sp_scores.p, 0, static_cast<uint64_t*>(nullptr));
     prof_end(e);
   }
   VR_HIP(hipGetLastError());
   return 0;
+}
+
+int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
+                  const uint8_t* mask_dev, bool weights_given) {
+  return sparse_run(e, q_idx_host, q_val_host, nnz, mask_dev, weights_given, 0, nullptr);
+}
+
+int sparse_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, int k,
+                     const uint8_t* mask_dev, bool weights_given, uint64_t* out_keys_dev) {
+  VR_CHECK(k >= 1 && k <= kListLen, "fused selection serves k <= %d", kListLen);
+  return sparse_run(e, q_idx_host, q_val_host, nnz, mask_dev, weights_given, k, out_keys_dev);
 }
 
 // ---- delete -----------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 // the corpus sizes of BASELINE.json (<= 4 MB per query) is served from L2 / Infinity Cache.
 
 #include "engine_internal.h"
+#include "topk_device.h"
 
 namespace vr {
 
@@ -96,6 +97,126 @@ __global__ __launch_bounds__(THREADS) void select_from_keys_kernel(const uint64_
     keys[i] = j < count ? s[j] : 0ull;
   }
   block_extract_topk<THREADS, ITEMS>(keys, k, out + (static_cast<int64_t>(q) * gridDim.x + seg) * k);
+}
+
+// ---- merging sorted candidate lists ----------------------------------------------------------
+
+// Two descending 64-entry lists -> their 64 best, descending, one entry per lane.
+// C[i] = max(A[i], B[63-i]) is a bitonic sequence holding the 64 largest of the union; six
+// half-cleaner steps sort it.
+__device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b_reversed, int lane) {
+  uint64_t v = a > b_reversed ? a : b_reversed;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint64_t p = __shfl_xor(v, d);
+    const bool keep_max = (lane & d) == 0;
+    v = keep_max ? (v > p ? v : p) : (v < p ? v : p);
+  }
+  return v;
+}
+
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeWaves = kMergeThreads / 64;
+constexpr int kMergeMaxLists = 512;                                   // = kScanBlocks
+constexpr int kMergePairsPerWave = kMergeMaxLists / 2 / kMergeWaves;  // 16 at the first level
+constexpr int kGatherCap = 2048;  // candidates the fast path ranks in LDS; beyond: tournament
+
+// One block per query: a tournament over the query's lists, halving their number per level.
+// Level 1 reads the lists from global memory, later levels from LDS (256 lists x 512 B = 128 KiB).
+__global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(const uint64_t* __restrict__ cand,
+                                                                     int n_lists, int k,
+                                                                     uint64_t* __restrict__ out) {
+  __shared__ uint64_t lds_lists[(kMergeMaxLists / 2) * kListLen];  // 128 KiB of the CU's 160 KiB
+  __shared__ uint64_t wave_thr[kMergeWaves];
+  __shared__ int gathered;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint64_t* in = cand + static_cast<int64_t>(blockIdx.x) * n_lists * kListLen;
+
+  // Fast path. The k-th key of ANY list is a lower bound T of the global k-th key, so only keys
+  // >= max_lists(T) can be in the answer: usually k plus a handful. Gather them, rank them.
+  {
+    uint64_t t = 0;
+    for (int l = threadIdx.x; l < n_lists; l += kMergeThreads) {
+      const uint64_t v = in[l * kListLen + (k - 1)];
+      t = v > t ? v : t;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint64_t o = __shfl_xor(t, off);
+      t = o > t ? o : t;
+    }
+    if (lane == 0) wave_thr[wave] = t;
+    if (threadIdx.x == 0) gathered = 0;
+    __syncthreads();
+    uint64_t thr = 0;
+#pragma unroll
+    for (int w = 0; w < kMergeWaves; ++w) thr = wave_thr[w] > thr ? wave_thr[w] : thr;
+    uint64_t* gat = lds_lists;  // reused as the gather buffer
+    for (int l = wave; l < n_lists; l += kMergeWaves) {
+      const uint64_t key = in[l * kListLen + lane];
+      const bool take = lane < k && key != 0 && key >= thr;
+      const uint64_t m = __ballot(take);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&gathered, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (take && slot < kGatherCap) gat[slot] = key;
+      }
+    }
+    __syncthreads();
+    const int c = gathered;
+    if (c <= kGatherCap) {  // block-uniform
+      for (int i = threadIdx.x; i < c; i += kMergeThreads) {
+        const uint64_t key = gat[i];
+        int rank = 0;
+        for (int j = 0; j < c; ++j) rank += gat[j] > key;
+        if (rank < k) out[static_cast<int64_t>(blockIdx.x) * k + rank] = key;
+      }
+      for (int i = c + threadIdx.x; i < k; i += kMergeThreads) out[static_cast<int64_t>(blockIdx.x) * k + i] = 0;
+      return;
+    }
+    __syncthreads();  // the tournament below reuses lds_lists
+  }
+  int n = n_lists;
+  bool first = true;
+  while (n > 1) {
+    const int pairs = (n + 1) / 2;
+    uint64_t res[kMergePairsPerWave];
+#pragma unroll
+    for (int j = 0; j < kMergePairsPerWave; ++j) {
+      const int p = wave + j * kMergeWaves;
+      res[j] = 0;
+      if (p < pairs) {
+        const uint64_t* src = first ? in : lds_lists;
+        const uint64_t a = src[(2 * p) * kListLen + lane];
+        const uint64_t b = (2 * p + 1 < n) ? src[(2 * p + 1) * kListLen + (63 - lane)] : 0ull;
+        res[j] = merge64(a, b, lane);
+      }
+    }
+    __syncthreads();  // every read of this level is done before slots are overwritten
+#pragma unroll
+    for (int j = 0; j < kMergePairsPerWave; ++j) {
+      const int p = wave + j * kMergeWaves;
+      if (p < pairs) lds_lists[p * kListLen + lane] = res[j];
+    }
+    __syncthreads();
+    n = pairs;
+    first = false;
+  }
+  if (wave == 0 && lane < k) {
+    const uint64_t v = first ? in[lane] : lds_lists[lane];
+    out[static_cast<int64_t>(blockIdx.x) * k + lane] = v;
+  }
+}
+
+int topk_merge_lists(vr_engine* e, const uint64_t* cand, int n_lists, int nq, int k, uint64_t* out) {
+  VR_CHECK(k >= 1 && k <= kListLen && n_lists >= 1 && n_lists <= kMergeMaxLists, "bad merge shape");
+  hipLaunchKernelGGL(merge_lists_kernel, dim3(static_cast<unsigned>(nq)), dim3(kMergeThreads), 0, e->stream,
+                     cand, n_lists, k, out);
+  VR_HIP(hipGetLastError());
+  return 0;
 }
 
 int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, int nq, int k,
