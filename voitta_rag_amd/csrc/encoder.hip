@@ -28,8 +28,15 @@ namespace vr {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+struct SplitWeight {  // f16x3 mode: w * 2^s as (hi, lo) f16, [out][in]; unscale = 2^-s
+  _Float16* hi = nullptr;
+  _Float16* lo = nullptr;
+  float unscale = 1.0f;
+};
+
 struct LayerWeights {
   float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+  SplitWeight s_qkv, s_o, s_1, s_2;
 };
 
 struct Encoder {
@@ -40,6 +47,7 @@ struct Encoder {
   // workspace for up to ws_tokens packed tokens
   int64_t ws_tokens = 0;
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+  float* xs = nullptr;  // f16x3 mode: the hidden state split as (hi, lo) f16 — T*H halfs each
   DevArray<int32_t> ids, cu;
   DevArray<float> out;
 };
@@ -54,11 +62,33 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kMaxPairs = 8;  // H <= 1024: H/128 float2 per lane
 
-// LayerNorm of one row held as float2 pairs per lane (biased variance, eps inside the sqrt)
+// ---- split precision (f16x3) ---------------------------------------------------------------------
+// A GEMM operand v is carried as two f16 numbers, hi = f16(v) and lo = f16(v - hi): together 22
+// significant bits. The product a*w is then a_hi*w_hi + a_hi*w_lo + a_lo*w_hi (the dropped
+// a_lo*w_lo term is < 2^-22 relative), three passes of the f16 MFMA whose products are exact in
+// its f32 accumulator — f32-class accuracy at 16/3 of the f32-MFMA rate. Activations are O(1) so
+// they are split unscaled (absolute granularity 2^-24, f16's subnormal spacing); values beyond
+// f16's range are clamped. Weights are pre-scaled by a power of two per tensor (exact).
+using half_t = _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
+  v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+  hi = static_cast<half_t>(v);
+  lo = static_cast<half_t>(v - static_cast<float>(hi));
+}
+
+struct half2_t {
+  half_t x, y;
+};
+
+// LayerNorm of one row held as float2 pairs per lane (biased variance, eps inside the sqrt).
+// out_hi/out_lo (optional): the same row split for the f16x3 GEMMs.
 __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs, int H,
                                               const float* __restrict__ g,
                                               const float* __restrict__ b, float eps, int lane,
-                                              float* __restrict__ out) {
+                                              float* __restrict__ out, half_t* __restrict__ out_hi = nullptr,
+                                              half_t* __restrict__ out_lo = nullptr) {
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < kMaxPairs; ++i)
@@ -83,6 +113,13 @@ __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs,
       o.x = (v[i].x - mean) * inv * gg.x + bb.x;
       o.y = (v[i].y - mean) * inv * gg.y + bb.y;
       *reinterpret_cast<float2*>(out + e) = o;
+      if (out_hi) {
+        half2_t h, l;
+        split_f16(o.x, h.x, l.x);
+        split_f16(o.y, h.y, l.y);
+        *reinterpret_cast<half2_t*>(out_hi + e) = h;
+        *reinterpret_cast<half2_t*>(out_lo + e) = l;
+      }
     }
 }
 
@@ -95,7 +132,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ type,
                                                        const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps,
-                                                       float* __restrict__ x) {
+                                                       float* __restrict__ x, half_t* __restrict__ x_hi,
+                                                       half_t* __restrict__ x_lo) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -121,13 +159,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       v[i].x = w.x + pp.x + tt.x;
       v[i].y = w.y + pp.y + tt.y;
     }
-  row_layernorm(v, pairs, H, g, b, eps, lane, x + static_cast<int64_t>(t) * H);
+  const int64_t o = static_cast<int64_t>(t) * H;
+  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + o : nullptr, x_lo ? x_lo + o : nullptr);
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int T, int H,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, float eps,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, half_t* __restrict__ out_hi,
+                                                        half_t* __restrict__ out_lo) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -136,7 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < kMaxPairs; ++i)
     if (i < pairs) v[i] = *reinterpret_cast<const float2*>(in + static_cast<int64_t>(t) * H + (i * 64 + lane) * 2);
-  row_layernorm(v, pairs, H, g, b, eps, lane, out + static_cast<int64_t>(t) * H);
+  const int64_t o = static_cast<int64_t>(t) * H;
+  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + o : nullptr, out_lo ? out_lo + o : nullptr);
 }
 
 // one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
@@ -336,6 +377,196 @@ static int launch_gemm(vr_engine* e, int epi, const float* A, const float* W, co
   return 0;
 }
 
+// ---- GEMM, split precision: C = (A_hi + A_lo)(W_hi + W_lo)^T * unscale + bias ... ---------------------
+
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 32;  // block tile (f16 elements along K)
+constexpr int HLDT = HBK_ + 8;                     // padded LDS row: 40 halfs = 80 B, 16-B aligned
+
+// Same 128x128 block / 64x64 wave decomposition as gemm_f32_kernel, on v_mfma_f32_32x32x16_f16:
+// per 16-deep k-step a wave reads hi and lo fragments of 2 A tiles and 2 B tiles (8 ds_read_b128)
+// and issues 2*2*3 MFMAs (hi*hi, hi*lo, lo*hi) into one f32 accumulator per tile.
+// EPI_BIAS: f32 out. EPI_BIAS_GELU: split (hi, lo) out only. EPI_BIAS_RESIDUAL: + R, f32 out.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16x3_kernel(
+    const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
+    const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
+    float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
+    float unscale) {
+  __shared__ half_t lds[2 * 4 * HBM_ * HLDT];  // [buf][Ah, Al, Wh, Wl][128][HLDT] = 80 KiB
+  const int tiles_n = N / HBN_;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+  const int bm = (swz / tiles_n) * HBM_;
+  const int bn = (swz % tiles_n) * HBN_;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging: a 128 x 32 f16 tile is 512 x 16 B; thread t moves the 16-B piece (row t>>2, col (t&3)*8)
+  // of rows 0..63 and 64..127 of each of the four arrays
+  const int lrow = tid >> 2;
+  const int lcol = (tid & 3) * 8;
+  const int last = M - 1;
+  const int64_t a_off0 = static_cast<int64_t>(min(bm + lrow, last)) * K + lcol;
+  const int64_t a_off1 = static_cast<int64_t>(min(bm + lrow + 64, last)) * K + lcol;
+  const int64_t w_off0 = static_cast<int64_t>(bn + lrow) * K + lcol;
+  const int64_t w_off1 = static_cast<int64_t>(bn + lrow + 64) * K + lcol;
+  uint4 r_ah0, r_ah1, r_al0, r_al1, r_wh0, r_wh1, r_wl0, r_wl1;
+#define VR_HLOAD(k0)                                                      \
+  do {                                                                    \
+    r_ah0 = *reinterpret_cast<const uint4*>(Ah + a_off0 + (k0));          \
+    r_ah1 = *reinterpret_cast<const uint4*>(Ah + a_off1 + (k0));          \
+    r_al0 = *reinterpret_cast<const uint4*>(Al + a_off0 + (k0));          \
+    r_al1 = *reinterpret_cast<const uint4*>(Al + a_off1 + (k0));          \
+    r_wh0 = *reinterpret_cast<const uint4*>(Wh + w_off0 + (k0));          \
+    r_wh1 = *reinterpret_cast<const uint4*>(Wh + w_off1 + (k0));          \
+    r_wl0 = *reinterpret_cast<const uint4*>(Wl + w_off0 + (k0));          \
+    r_wl1 = *reinterpret_cast<const uint4*>(Wl + w_off1 + (k0));          \
+  } while (0)
+#define VR_HSTORE(buf)                                                    \
+  do {                                                                    \
+    half_t* d = lds + (buf) * 4 * HBM_ * HLDT + lrow * HLDT + lcol;       \
+    *reinterpret_cast<uint4*>(d) = r_ah0;                                 \
+    *reinterpret_cast<uint4*>(d + 64 * HLDT) = r_ah1;                     \
+    *reinterpret_cast<uint4*>(d + HBM_ * HLDT) = r_al0;                   \
+    *reinterpret_cast<uint4*>(d + HBM_ * HLDT + 64 * HLDT) = r_al1;       \
+    *reinterpret_cast<uint4*>(d + 2 * HBM_ * HLDT) = r_wh0;               \
+    *reinterpret_cast<uint4*>(d + 2 * HBM_ * HLDT + 64 * HLDT) = r_wh1;   \
+    *reinterpret_cast<uint4*>(d + 3 * HBM_ * HLDT) = r_wl0;               \
+    *reinterpret_cast<uint4*>(d + 3 * HBM_ * HLDT + 64 * HLDT) = r_wl1;   \
+  } while (0)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk = K / HBK_;
+  VR_HLOAD(0);
+  VR_HSTORE(0);
+  __syncthreads();
+
+  // 32x32x16 f16 operands: lane l supplies row/col (l & 31), k = 8*(l >> 5) + j, j = 0..7 (16 B)
+  const int frow = lane & 31;
+  const int fk = 8 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) VR_HLOAD((kt + 1) * HBK_);
+    const half_t* base = lds + buf * 4 * HBM_ * HLDT;
+    const half_t* pa = base + (wm * 64 + frow) * HLDT + fk;
+    const half_t* pw = base + 2 * HBM_ * HLDT + (wn * 64 + frow) * HLDT + fk;
+#pragma unroll
+    for (int kk = 0; kk < HBK_; kk += 16) {
+      f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(pa + i * 32 * HLDT + kk);
+        al[i] = *reinterpret_cast<const f16x8*>(pa + HBM_ * HLDT + i * 32 * HLDT + kk);
+        wh[i] = *reinterpret_cast<const f16x8*>(pw + i * 32 * HLDT + kk);
+        wl[i] = *reinterpret_cast<const f16x8*>(pw + HBM_ * HLDT + i * 32 * HLDT + kk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) VR_HSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef VR_HLOAD
+#undef VR_HSTORE
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = bn + wn * 64 + j * 32 + (lane & 31);
+      const float bs = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][r] * unscale + bs;
+          const int64_t o = static_cast<int64_t>(row) * N + col;
+          if (EPI == EPI_BIAS_GELU) {
+            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            half_t h, l;
+            split_f16(v, h, l);
+            Ch[o] = h;
+            Cl[o] = l;
+          } else {
+            if (EPI == EPI_BIAS_RESIDUAL) v += R[o];
+            C[o] = v;
+          }
+        }
+      }
+    }
+}
+
+// weights: w * scale -> (hi, lo); scale is a power of two chosen from max|w| of the tensor
+__global__ void absmax_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
+  float m = 0.0f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 8));
+  m = fmaxf(m, __shfl_xor(m, 4));
+  m = fmaxf(m, __shfl_xor(m, 2));
+  m = fmaxf(m, __shfl_xor(m, 1));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order as uints
+}
+
+__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, float scale,
+                                     half_t* __restrict__ hi, half_t* __restrict__ lo) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) {
+    half_t h, l;
+    split_f16(w[i] * scale, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half_t* Al, const half_t* Wh,
+                             const half_t* Wl, float unscale, const float* bias, const float* R, float* C,
+                             half_t* Ch, half_t* Cl, int M, int N, int K) {
+  VR_CHECK(N % HBN_ == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, HBN_, HBK_);
+  if (M <= 0) return 0;
+  hipStream_t s = e->stream;
+  const int grid = ((M + HBM_ - 1) / HBM_) * (N / HBN_);
+  prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R, C, Ch,
+                         Cl, M, N, K, unscale);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R,
+                         C, Ch, Cl, M, N, K, unscale);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_RESIDUAL>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias,
+                         R, C, Ch, Cl, M, N, K, unscale);
+      break;
+  }
+  prof_end(e);
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- attention -----------------------------------------------------------------------------------
 
 // One block = 64 queries of one (sequence, head); wave w owns queries 16w..16w+15.
@@ -346,7 +577,8 @@ template <int DH>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu, int seq0,
                                                         int tok_base, int H, int qblocks, float scale,
-                                                        float* __restrict__ ctx) {
+                                                        float* __restrict__ ctx, half_t* __restrict__ ctx_hi,
+                                                        half_t* __restrict__ ctx_lo) {
   constexpr int LDK = DH + 4;
   constexpr int NS = DH / 16;  // 16-wide d blocks
   __shared__ float sK[64 * LDK];
@@ -447,11 +679,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   l += __shfl_xor(l, 32);
   if (q_valid) {
     const float inv = 1.0f / l;
-    float* op = ctx + static_cast<int64_t>(t0 + q_tok) * H + head * DH + 4 * g;
+    const int64_t off = static_cast<int64_t>(t0 + q_tok) * H + head * DH + 4 * g;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       float4 v = make_float4(o[s][0] * inv, o[s][1] * inv, o[s][2] * inv, o[s][3] * inv);
-      *reinterpret_cast<float4*>(op + 16 * s) = v;
+      if (ctx_hi) {  // f16x3 mode: the only consumer is the output-projection GEMM
+        half_t h[4], lo[4];
+        split_f16(v.x, h[0], lo[0]);
+        split_f16(v.y, h[1], lo[1]);
+        split_f16(v.z, h[2], lo[2]);
+        split_f16(v.w, h[3], lo[3]);
+        *reinterpret_cast<uint2*>(ctx_hi + off + 16 * s) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(ctx_lo + off + 16 * s) = *reinterpret_cast<const uint2*>(lo);
+      } else {
+        *reinterpret_cast<float4*>(ctx + off + 16 * s) = v;
+      }
     }
   }
 }
@@ -466,6 +708,37 @@ static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_
     VR_HIP(hipMemcpyAsync(p, src, n_floats * sizeof(float),
                           mem == VR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e->stream));
   *out = p;
+  return 0;
+}
+
+// w (device, n floats) -> scaled (hi, lo) f16 pair; scale = 2^s puts max|w| into [1024, 2048)
+static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, SplitWeight* out) {
+  float* scratch = nullptr;
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, 1, 0, &scratch));
+  VR_HIP(hipMemsetAsync(scratch, 0, sizeof(float), e->stream));
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>(1024, (n + 255) / 256));
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, e->stream, w_dev, static_cast<int64_t>(n),
+                     reinterpret_cast<unsigned int*>(scratch));
+  float m = 0.0f;
+  VR_HIP(hipMemcpyAsync(&m, scratch, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  VR_CHECK(std::isfinite(m), "weight tensor holds a non-finite value");
+  int s = 0;
+  if (m > 0.0f) {
+    int ex = 0;
+    (void)std::frexp(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+    s = 11 - ex;
+  }
+  const float scale = std::ldexp(1.0f, s);
+  out->unscale = std::ldexp(1.0f, -s);
+  float *hi = nullptr, *lo = nullptr;
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, (n + 1) / 2, 0, &hi));
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, (n + 1) / 2, 0, &lo));
+  out->hi = reinterpret_cast<_Float16*>(hi);
+  out->lo = reinterpret_cast<_Float16*>(lo);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream,
+                     w_dev, static_cast<int64_t>(n), scale, out->hi, out->lo);
+  VR_HIP(hipGetLastError());
   return 0;
 }
 
@@ -494,6 +767,8 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
            "head size %d unsupported (32 or 64)", d->heads ? H / d->heads : 0);
   VR_CHECK(n_tensors == 5 + 16 * L, "expected %d tensors, got %d", 5 + 16 * L, n_tensors);
   VR_CHECK(d->pooling == 0 || d->pooling == 1, "pooling must be 0 (mean) or 1 (cls)");
+  VR_CHECK(d->precision == VR_PRECISION_F32 || d->precision == VR_PRECISION_F16X3, "unknown precision %d",
+           d->precision);
   for (int i = 0; i < n_tensors; ++i) VR_CHECK(t[i] != nullptr, "tensor %d is null", i);
   encoder_release(e);
   Encoder* enc = new Encoder();
@@ -525,6 +800,12 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
     VR_TRY(dev_alloc_copy(e, enc, w[13], H, mem, &lw.b2));
     VR_TRY(dev_alloc_copy(e, enc, w[14], H, mem, &lw.ln2g));
     VR_TRY(dev_alloc_copy(e, enc, w[15], H, mem, &lw.ln2b));
+    if (d->precision == VR_PRECISION_F16X3) {
+      VR_TRY(make_split(e, enc, lw.wqkv, 3 * HH, &lw.s_qkv));
+      VR_TRY(make_split(e, enc, lw.wo, HH, &lw.s_o));
+      VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, &lw.s_1));
+      VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, &lw.s_2));
+    }
     enc->layers.push_back(lw);
   }
   VR_HIP(hipStreamSynchronize(e->stream));  // host sources may be freed by the caller now
@@ -534,7 +815,7 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
 static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   if (tokens <= enc->ws_tokens) return 0;
   VR_HIP(hipStreamSynchronize(e->stream));
-  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn}) {
+  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs}) {
     if (*p) {
       enc->owned.erase(std::remove(enc->owned.begin(), enc->owned.end(), *p), enc->owned.end());
       (void)hipFree(*p);
@@ -548,6 +829,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->ctx));
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->tmp));
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * I, 0, &enc->ffn));
+  if (enc->d.precision == VR_PRECISION_F16X3) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->xs));
   enc->ws_tokens = tokens;
   return 0;
 }
@@ -560,29 +842,54 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   const int H = d.hidden, I = d.intermediate, nh = d.heads, dh = H / nh;
   hipStream_t s = e->stream;
   const unsigned row_blocks = static_cast<unsigned>((T + 3) / 4);
+  // f16x3 mode: every GEMM input also exists as (hi, lo) f16. The split hidden state lives in xs;
+  // the context and the FFN intermediate are ONLY needed split, so they reuse the f32 buffers.
+  const bool split = d.precision == VR_PRECISION_F16X3;
+  const int64_t TH = static_cast<int64_t>(T) * H, TI = static_cast<int64_t>(T) * I;
+  half_t* xh = split ? reinterpret_cast<half_t*>(enc->xs) : nullptr;
+  half_t* xl = split ? xh + TH : nullptr;
+  half_t* ch = split ? reinterpret_cast<half_t*>(enc->ctx) : nullptr;
+  half_t* cl = split ? ch + TH : nullptr;
+  half_t* fh = split ? reinterpret_cast<half_t*>(enc->ffn) : nullptr;
+  half_t* fl = split ? fh + TI : nullptr;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
-                     enc->x);
+                     enc->x, xh, xl);
   const int qblocks = (max_len + 63) / 64;
   const float scale = 1.0f / sqrtf(static_cast<float>(dh));
   for (const LayerWeights& w : enc->layers) {
-    VR_TRY(launch_gemm(e, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
+    if (split)
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
+                               enc->qkv, nullptr, nullptr, T, 3 * H, H));
+    else
+      VR_TRY(launch_gemm(e, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
     dim3 agrid(static_cast<unsigned>((seq1 - seq0) * qblocks), static_cast<unsigned>(nh));
     prof_begin(e, VR_PROF_ATTENTION, attn_flop);
     if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
-                         qblocks, scale, enc->ctx);
+                         qblocks, scale, enc->ctx, ch, cl);
     else
       hipLaunchKernelGGL((attention_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
-                         qblocks, scale, enc->ctx);
+                         qblocks, scale, enc->ctx, ch, cl);
     prof_end(e);
-    VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
+    if (split)
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, ch, cl, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, enc->x,
+                               enc->tmp, nullptr, nullptr, T, H, H));
+    else
+      VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln1g, w.ln1b,
-                       d.eps, enc->x);
-    VR_TRY(launch_gemm(e, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
-    VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
+                       d.eps, enc->x, xh, xl);
+    if (split) {
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, xl, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr,
+                               nullptr, fh, fl, T, I, H));
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, fh, fl, w.s_2.hi, w.s_2.lo, w.s_2.unscale, w.b2, enc->x,
+                               enc->tmp, nullptr, nullptr, T, H, I));
+    } else {
+      VR_TRY(launch_gemm(e, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
+      VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln2g, w.ln2b,
-                       d.eps, enc->x);
+                       d.eps, enc->x, xh, xl);
   }
   hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(seq1 - seq0)), dim3(256), 0, s, enc->x, cu_dev,
                      seq0, tok_base, H, d.pooling, d.normalize, out_dev);

@@ -45,6 +45,7 @@ class BertDesc:
     pooling: str = "mean"  # "mean" | "cls"
     normalize: bool = True
     eps: float = 1e-12
+    precision: str = "f32"  # "f32" (exact f32 MFMA) | "f16x3" (split-precision f16 MFMA, f32-class accuracy)
 
     def to_c(self) -> _lib.VrBertDesc:
         d = _lib.VrBertDesc()
@@ -54,6 +55,9 @@ class BertDesc:
         d.pooling = VR_POOL_CLS if self.pooling == "cls" else VR_POOL_MEAN
         d.normalize = int(self.normalize)
         d.eps = self.eps
+        if self.precision not in ("f32", "f16x3"):
+            raise ValueError(f"unknown encoder precision {self.precision!r}")
+        d.precision = _lib.VR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.VR_PRECISION_F32
         return d
 
 
