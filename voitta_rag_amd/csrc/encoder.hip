@@ -226,6 +226,20 @@ constexpr int LDT = BK + 4;  // padded LDS row (floats); rows stay 16-byte align
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
 
+// Linear tile id -> (row panel, column panel), row panels taken kGroupM at a time with the column
+// index slow inside a group. The ~32 blocks an XCD runs together then cover ~8 row panels x ~4
+// column panels, so both operands' working set (~4 MB per sweep of K) fits the XCD's 4-MiB L2;
+// with the plain column-fastest order all of W (7-9 MB) cycles through L2 for every row panel.
+constexpr int kGroupM = 8;
+__device__ __forceinline__ void grouped_tile(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int per_group = kGroupM * tiles_n;
+  const int group = id / per_group;
+  const int within = id - group * per_group;
+  const int gm = min(kGroupM, tiles_m - group * kGroupM);
+  tm = group * kGroupM + within % gm;
+  tn = within / gm;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ W,
@@ -243,8 +257,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int bid = blockIdx.x;
   const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-  const int bm = (swz / tiles_n) * BM;
-  const int bn = (swz % tiles_n) * BN;
+  int tm, tn;
+  grouped_tile(swz, (M + BM - 1) / BM, tiles_n, tm, tn);
+  const int bm = tm * BM;
+  const int bn = tn * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -379,65 +395,67 @@ static int launch_gemm(vr_engine* e, int epi, const float* A, const float* W, co
 
 // ---- GEMM, split precision: C = (A_hi + A_lo)(W_hi + W_lo)^T * unscale + bias ... ---------------------
 
-constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 32;  // block tile (f16 elements along K)
-constexpr int HLDT = HBK_ + 8;                     // padded LDS row: 40 halfs = 80 B, 16-B aligned
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64;  // block tile; 64 f16 along K = one 128-B line per row
+constexpr int HLDT = HBK_ + 8;                     // padded LDS row: 72 halfs = 144 B (conflict-free b128 reads)
 
 // Same 128x128 block / 64x64 wave decomposition as gemm_f32_kernel, on v_mfma_f32_32x32x16_f16:
 // per 16-deep k-step a wave reads hi and lo fragments of 2 A tiles and 2 B tiles (8 ds_read_b128)
 // and issues 2*2*3 MFMAs (hi*hi, hi*lo, lo*hi) into one f32 accumulator per tile.
+// Staging moves whole 128-B lines (8 lanes x 16 B per row): the next K-tile is loaded into
+// registers while the current one is multiplied out of the single 72-KiB LDS image (2 blocks/CU).
 // EPI_BIAS: f32 out. EPI_BIAS_GELU: split (hi, lo) out only. EPI_BIAS_RESIDUAL: + R, f32 out.
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
     const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
     float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
-    float unscale) {
-  __shared__ half_t lds[2 * 4 * HBM_ * HLDT];  // [buf][Ah, Al, Wh, Wl][128][HLDT] = 80 KiB
+    float unscale, int ablate) {
+  __shared__ half_t lds[4 * HBM_ * HLDT];  // [Ah, Al, Wh, Wl][128][HLDT] = 72 KiB
   const int tiles_n = N / HBN_;
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-  const int bm = (swz / tiles_n) * HBM_;
-  const int bn = (swz % tiles_n) * HBN_;
+  int tm, tn;
+  grouped_tile(swz, (M + HBM_ - 1) / HBM_, tiles_n, tm, tn);
+  const int bm = tm * HBM_;
+  const int bn = tn * HBN_;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // staging: a 128 x 32 f16 tile is 512 x 16 B; thread t moves the 16-B piece (row t>>2, col (t&3)*8)
-  // of rows 0..63 and 64..127 of each of the four arrays
-  const int lrow = tid >> 2;
-  const int lcol = (tid & 3) * 8;
+  // staging: thread t moves the 16-B piece (t & 7) of rows (t >> 3) + 32p, p = 0..3, of each array
+  const int lrow = tid >> 3;
+  const int lcol = (tid & 7) * 8;
   const int last = M - 1;
+  // (named registers, not arrays: arrays indexed inside macros ended up in scratch memory)
   const int64_t a_off0 = static_cast<int64_t>(min(bm + lrow, last)) * K + lcol;
-  const int64_t a_off1 = static_cast<int64_t>(min(bm + lrow + 64, last)) * K + lcol;
+  const int64_t a_off1 = static_cast<int64_t>(min(bm + lrow + 32, last)) * K + lcol;
+  const int64_t a_off2 = static_cast<int64_t>(min(bm + lrow + 64, last)) * K + lcol;
+  const int64_t a_off3 = static_cast<int64_t>(min(bm + lrow + 96, last)) * K + lcol;
   const int64_t w_off0 = static_cast<int64_t>(bn + lrow) * K + lcol;
-  const int64_t w_off1 = static_cast<int64_t>(bn + lrow + 64) * K + lcol;
-  uint4 r_ah0, r_ah1, r_al0, r_al1, r_wh0, r_wh1, r_wl0, r_wl1;
-#define VR_HLOAD(k0)                                                      \
-  do {                                                                    \
-    r_ah0 = *reinterpret_cast<const uint4*>(Ah + a_off0 + (k0));          \
-    r_ah1 = *reinterpret_cast<const uint4*>(Ah + a_off1 + (k0));          \
-    r_al0 = *reinterpret_cast<const uint4*>(Al + a_off0 + (k0));          \
-    r_al1 = *reinterpret_cast<const uint4*>(Al + a_off1 + (k0));          \
-    r_wh0 = *reinterpret_cast<const uint4*>(Wh + w_off0 + (k0));          \
-    r_wh1 = *reinterpret_cast<const uint4*>(Wh + w_off1 + (k0));          \
-    r_wl0 = *reinterpret_cast<const uint4*>(Wl + w_off0 + (k0));          \
-    r_wl1 = *reinterpret_cast<const uint4*>(Wl + w_off1 + (k0));          \
+  const int64_t w_step = static_cast<int64_t>(32) * K;
+  uint4 r_ah0, r_ah1, r_ah2, r_ah3, r_al0, r_al1, r_al2, r_al3;
+  uint4 r_wh0, r_wh1, r_wh2, r_wh3, r_wl0, r_wl1, r_wl2, r_wl3;
+#define VR_HLOAD1(P, k0)                                                              \
+  r_ah##P = *reinterpret_cast<const uint4*>(Ah + a_off##P + (k0));                    \
+  r_al##P = *reinterpret_cast<const uint4*>(Al + a_off##P + (k0));                    \
+  r_wh##P = *reinterpret_cast<const uint4*>(Wh + w_off0 + P * w_step + (k0));         \
+  r_wl##P = *reinterpret_cast<const uint4*>(Wl + w_off0 + P * w_step + (k0));
+#define VR_HLOAD(k0) \
+  do {               \
+    VR_HLOAD1(0, k0) VR_HLOAD1(1, k0) VR_HLOAD1(2, k0) VR_HLOAD1(3, k0) \
   } while (0)
-#define VR_HSTORE(buf)                                                    \
-  do {                                                                    \
-    half_t* d = lds + (buf) * 4 * HBM_ * HLDT + lrow * HLDT + lcol;       \
-    *reinterpret_cast<uint4*>(d) = r_ah0;                                 \
-    *reinterpret_cast<uint4*>(d + 64 * HLDT) = r_ah1;                     \
-    *reinterpret_cast<uint4*>(d + HBM_ * HLDT) = r_al0;                   \
-    *reinterpret_cast<uint4*>(d + HBM_ * HLDT + 64 * HLDT) = r_al1;       \
-    *reinterpret_cast<uint4*>(d + 2 * HBM_ * HLDT) = r_wh0;               \
-    *reinterpret_cast<uint4*>(d + 2 * HBM_ * HLDT + 64 * HLDT) = r_wh1;   \
-    *reinterpret_cast<uint4*>(d + 3 * HBM_ * HLDT) = r_wl0;               \
-    *reinterpret_cast<uint4*>(d + 3 * HBM_ * HLDT + 64 * HLDT) = r_wl1;   \
+#define VR_HSTORE1(P)                                                                 \
+  *reinterpret_cast<uint4*>(lds + (lrow + 32 * P) * HLDT + lcol) = r_ah##P;                          \
+  *reinterpret_cast<uint4*>(lds + HBM_ * HLDT + (lrow + 32 * P) * HLDT + lcol) = r_al##P;            \
+  *reinterpret_cast<uint4*>(lds + 2 * HBM_ * HLDT + (lrow + 32 * P) * HLDT + lcol) = r_wh##P;        \
+  *reinterpret_cast<uint4*>(lds + 3 * HBM_ * HLDT + (lrow + 32 * P) * HLDT + lcol) = r_wl##P;
+#define VR_HSTORE() \
+  do {              \
+    VR_HSTORE1(0) VR_HSTORE1(1) VR_HSTORE1(2) VR_HSTORE1(3) \
   } while (0)
 
   f32x16 acc[2][2];
@@ -450,18 +468,16 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
 
   const int nk = K / HBK_;
   VR_HLOAD(0);
-  VR_HSTORE(0);
+  VR_HSTORE();
   __syncthreads();
 
   // 32x32x16 f16 operands: lane l supplies row/col (l & 31), k = 8*(l >> 5) + j, j = 0..7 (16 B)
   const int frow = lane & 31;
   const int fk = 8 * (lane >> 5);
+  const half_t* pa = lds + (wm * 64 + frow) * HLDT + fk;
+  const half_t* pw = lds + 2 * HBM_ * HLDT + (wn * 64 + frow) * HLDT + fk;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) VR_HLOAD((kt + 1) * HBK_);
-    const half_t* base = lds + buf * 4 * HBM_ * HLDT;
-    const half_t* pa = base + (wm * 64 + frow) * HLDT + fk;
-    const half_t* pw = base + 2 * HBM_ * HLDT + (wn * 64 + frow) * HLDT + fk;
+    if (kt + 1 < nk && !(ablate & 2)) VR_HLOAD((kt + 1) * HBK_);
 #pragma unroll
     for (int kk = 0; kk < HBK_; kk += 16) {
       f16x8 ah[2], al[2], wh[2], wl[2];
@@ -476,42 +492,72 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          if (ablate & 4) continue;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) VR_HSTORE(buf ^ 1);
+    __syncthreads();  // every wave is done reading this K-tile
+    if (kt + 1 < nk) VR_HSTORE();
     __syncthreads();
   }
 #undef VR_HLOAD
+#undef VR_HLOAD1
 #undef VR_HSTORE
+#undef VR_HSTORE1
 
+  // Epilogue through LDS (free now: the loop ended on a barrier). In the MFMA's C layout a lane
+  // owns one column and 16 scattered rows, which gives 4-byte (or, split, 2-byte) stores — they
+  // cost a quarter of the kernel. Each wave parks its 64x64 tile in its own LDS region and reads
+  // it back by rows: 16 lanes x 16 B cover a 256-B row segment, bias / GELU / residual / split are
+  // applied on float4s, and every global access is 16 B (8 B for the f16 halves).
+  constexpr int SLD = 64 + 4;  // padded row of the staging tile (floats)
+  float* stage = reinterpret_cast<float*>(lds) + wave * (64 * SLD);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = bn + wn * 64 + j * 32 + (lane & 31);
-      const float bs = bias[col];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) {
-          float v = acc[i][j][r] * unscale + bs;
-          const int64_t o = static_cast<int64_t>(row) * N + col;
-          if (EPI == EPI_BIAS_GELU) {
-            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-            half_t h, l;
-            split_f16(v, h, l);
-            Ch[o] = h;
-            Cl[o] = l;
-          } else {
-            if (EPI == EPI_BIAS_RESIDUAL) v += R[o];
-            C[o] = v;
-          }
-        }
+      for (int r = 0; r < 16; ++r)
+        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();  // the region is private to this wave: no block barrier needed
+  const int c4 = (lane & 15) * 4;
+  const int gcol = bn + wn * 64 + c4;
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + gcol);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int lr = it * 4 + (lane >> 4);
+    const int grow = bm + wm * 64 + lr;
+    float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
+    if (grow >= M || ((ablate & 1) && v.x == v.x)) continue;
+    v.x = v.x * unscale + b4.x;
+    v.y = v.y * unscale + b4.y;
+    v.z = v.z * unscale + b4.z;
+    v.w = v.w * unscale + b4.w;
+    const int64_t o = static_cast<int64_t>(grow) * N + gcol;
+    if (EPI == EPI_BIAS_GELU) {
+      float g[4] = {v.x, v.y, v.z, v.w};
+      half_t h[4], l[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        g[c] = 0.5f * g[c] * (1.0f + erff(g[c] * 0.70710678118654752440f));
+        split_f16(g[c], h[c], l[c]);
       }
+      *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+      *reinterpret_cast<uint2*>(Cl + o) = *reinterpret_cast<const uint2*>(l);
+    } else {
+      if (EPI == EPI_BIAS_RESIDUAL) {
+        const float4 r4 = *reinterpret_cast<const float4*>(R + o);
+        v.x += r4.x;
+        v.y += r4.y;
+        v.z += r4.z;
+        v.w += r4.w;
+      }
+      *reinterpret_cast<float4*>(C + o) = v;
     }
+  }
 }
 
 // weights: w * scale -> (hi, lo); scale is a power of two chosen from max|w| of the tensor
@@ -547,19 +593,20 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   if (M <= 0) return 0;
   hipStream_t s = e->stream;
   const int grid = ((M + HBM_ - 1) / HBM_) * (N / HBN_);
+  static const int ablate = getenv("VR_GEMM_ABLATE") ? atoi(getenv("VR_GEMM_ABLATE")) : 0;  // timing experiments only
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
   switch (epi) {
     case EPI_BIAS:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R, C, Ch,
-                         Cl, M, N, K, unscale);
+                         Cl, M, N, K, unscale, ablate);
       break;
     case EPI_BIAS_GELU:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R,
-                         C, Ch, Cl, M, N, K, unscale);
+                         C, Ch, Cl, M, N, K, unscale, ablate);
       break;
     default:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_RESIDUAL>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias,
-                         R, C, Ch, Cl, M, N, K, unscale);
+                         R, C, Ch, Cl, M, N, K, unscale, ablate);
       break;
   }
   prof_end(e);
