@@ -275,19 +275,10 @@ __global__ __launch_bounds__(kScanWaves * 64) void dense_scan_topk_kernel(
       wave_offer(mine, k, k3, q, active, lane);
     }
   }
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < kScanWaves; ++w)
-      for (int qq = 0; qq < nq; ++qq) {
-        const uint64_t* other = lists + (w * nq + qq) * kListLen;
-        for (int i = 0; i < k; ++i) {
-          const uint64_t key = other[i];  // wave-uniform
-          if (key == 0) break;
-          wave_list_insert(mine + qq * kListLen, k, key, lane);
-        }
-      }
-    for (int qq = 0; qq < nq; ++qq)
-      cand[(static_cast<int64_t>(qq) * gridDim.x + blockIdx.x) * kListLen + lane] = mine[qq * kListLen + lane];
+  for (int qq = 0; qq < nq; ++qq) {  // fold the waves' lists of each query: log2(waves) merge rounds
+    block_merge_lists(lists + qq * kListLen, nq * kListLen, kScanWaves, wave, lane);
+    if (wave == 0)
+      cand[(static_cast<int64_t>(qq) * gridDim.x + blockIdx.x) * kListLen + lane] = lists[qq * kListLen + lane];
   }
 }
 

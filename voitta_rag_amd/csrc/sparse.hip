@@ -211,7 +211,8 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
 // ---- query ------------------------------------------------------------------------------------
 
 constexpr int kQHash = 1024;   // LDS hash slots for the query terms
-constexpr int kSparseWaves = 8;  // 512-thread blocks, as the dense scan
+constexpr int kSparseWaves = 16;  // 1024-thread blocks: 2 per CU = every wave slot busy (the scan
+                                  // is a latency-bound gather; it wants all the loads in flight)
 
 // One kernel per sparse query. Prologue (every block, redundantly): read the <=256 sorted query
 // terms straight from the pinned host scratch, weight them — q_t * idf_t with idf from the
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kSparseWaves * 64) void sparse_scores_kernel(
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   uint64_t* list = lists + wave * kListLen;
-  lists[threadIdx.x] = 0ull;
+  lists[threadIdx.x] = 0ull;  // blockDim.x == kSparseWaves * kListLen
   for (int i = threadIdx.x; i < kQHash; i += kSparseWaves * 64) hk[i] = -1;
   if (static_cast<int>(threadIdx.x) < nnz) {
     const int32_t id = q_idx[threadIdx.x];
@@ -301,16 +302,8 @@ __global__ __launch_bounds__(kSparseWaves * 64) void sparse_scores_kernel(
     }
   }
   if (FUSED) {  // fold the block's lists into one: cand[block][64], descending, zero padded
-    __syncthreads();
-    if (wave == 0) {
-      for (int w = 1; w < kSparseWaves; ++w)
-        for (int i = 0; i < k; ++i) {
-          const uint64_t key = lists[w * kListLen + i];
-          if (key == 0) break;
-          wave_list_insert(list, k, key, lane);
-        }
-      cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
-    }
+    block_merge_lists(lists, kListLen, kSparseWaves, wave, lane);
+    if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
   }
 }
 

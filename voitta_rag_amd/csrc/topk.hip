@@ -101,20 +101,6 @@ __global__ __launch_bounds__(THREADS) void select_from_keys_kernel(const uint64_
 
 // ---- merging sorted candidate lists ----------------------------------------------------------
 
-// Two descending 64-entry lists -> their 64 best, descending, one entry per lane.
-// C[i] = max(A[i], B[63-i]) is a bitonic sequence holding the 64 largest of the union; six
-// half-cleaner steps sort it.
-__device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b_reversed, int lane) {
-  uint64_t v = a > b_reversed ? a : b_reversed;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint64_t p = __shfl_xor(v, d);
-    const bool keep_max = (lane & d) == 0;
-    v = keep_max ? (v > p ? v : p) : (v < p ? v : p);
-  }
-  return v;
-}
-
 constexpr int kMergeThreads = 1024;
 constexpr int kMergeWaves = kMergeThreads / 64;
 constexpr int kMergeMaxLists = 512;                                   // = kScanBlocks

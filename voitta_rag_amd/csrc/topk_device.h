@@ -52,4 +52,33 @@ __device__ __forceinline__ void wave_offer(uint64_t* lists, int k, uint64_t key,
   }
 }
 
+// Two descending 64-entry lists -> their 64 best, descending, one entry per lane.
+// C[i] = max(A[i], B[63-i]) is a bitonic sequence holding the 64 largest of the union; six
+// half-cleaner steps sort it.
+__device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b_reversed, int lane) {
+  uint64_t v = a > b_reversed ? a : b_reversed;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint64_t p = __shfl_xor(v, d);
+    const bool keep_max = (lane & d) == 0;
+    v = keep_max ? (v > p ? v : p) : (v < p ? v : p);
+  }
+  return v;
+}
+
+// Fold the per-wave lists of a block (lists[w * stride .. + kListLen), w < n_waves, n_waves a
+// power of two) into wave 0's list: log2(n_waves) rounds of pairwise merge64. Call from every
+// thread of the block.
+__device__ __forceinline__ void block_merge_lists(uint64_t* lists, int stride, int n_waves, int wave, int lane) {
+  for (int s = 1; s < n_waves; s <<= 1) {
+    __syncthreads();
+    uint64_t merged = 0;
+    const bool mine = (wave % (2 * s)) == 0;
+    if (mine) merged = merge64(lists[wave * stride + lane], lists[(wave + s) * stride + (63 - lane)], lane);
+    __syncthreads();
+    if (mine) lists[wave * stride + lane] = merged;
+  }
+  __syncthreads();
+}
+
 }  // namespace vr
