@@ -54,9 +54,19 @@ typedef struct vr_config {
   int32_t struct_size;   /* = sizeof(vr_config) */
   int32_t device;        /* HIP device ordinal */
   int32_t dim;           /* dense dimension D (multiple of 16): settings.embedding_dimension, embedding.py:20 */
-  int32_t reserved0;
+  int32_t flags;         /* VR_ENGINE_* bits */
   int64_t initial_rows;  /* capacity hint; tables grow by doubling */
 } vr_config;
+
+/* vr_config.flags.
+ * By default a single-query dense search over a store with dim % 32 == 0 runs in two stages:
+ * an f16 shadow copy of the corpus (1/2 of the bytes) is scanned with the f16 MFMA, a rigorous
+ * per-row error bound (the row's exact rounding residual, Cauchy-Schwarz) turns the approximate
+ * scores into lower/upper bounds, and every row whose upper bound reaches the k-th best lower
+ * bound is re-scored with the exact f32 chain. Results are bit-identical to the one-stage exact
+ * scan (tests run both); the flag below turns the shadow copy (+50 % memory) and the first
+ * stage off. */
+#define VR_ENGINE_NO_PREFILTER 1
 
 /* Search-time predicate; restates _build_filter, vector_store.py:462-530. All ids are the
  * host's dictionary ids of folder_path / index_folder strings (exact string equality in the
@@ -196,6 +206,12 @@ int vr_upsert(vr_engine* e, int64_t n, int mem,
  * :378-390,:419-431 once the host has resolved the filter to rows. Already-dead rows are ignored;
  * document frequencies and the sparse point count are decremented. */
 int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
+
+/* counters of the two-stage dense search (see VR_ENGINE_NO_PREFILTER) */
+#define VR_STAT_TWO_STAGE 0        /* single-query dense searches served by f16 scan + exact re-score */
+#define VR_STAT_FALLBACK 1         /* ... of which exceeded the re-score budget and were redone one-stage */
+#define VR_STAT_LAST_CANDIDATES 2  /* rows re-scored by the last two-stage search */
+int vr_stats(vr_engine* e, int32_t which, int64_t* out);
 
 /* n_rows = rows ever assigned, n_live = not tombstoned (get_collection_info, vector_store.py:699-710) */
 int vr_count(vr_engine* e, int64_t* n_rows, int64_t* n_live);

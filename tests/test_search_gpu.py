@@ -194,3 +194,69 @@ def test_rows_without_sparse_vectors_and_empty_engine(gpu):
     rows, scores, fd = e.search_hybrid(x[3], [], [], 5, 0.1)
     assert rows[0] == 3 and fd.all()
     e.close()
+
+
+@pytest.mark.parametrize("dim,n", [(768, 20000), (384, 9000), (1024, 5000), (64, 6000), (96, 5000)])
+def test_two_stage_dense_search_is_bit_identical(gpu, dim, n):
+    """Stores with dim % 32 == 0 and >= 4096 rows answer single-query dense searches through the
+    f16 prefilter + exact re-score (dense8.hip). Rows, scores and order must equal the oracle's —
+    and therefore the one-stage scan's — bit for bit, with filters and tombstones in play."""
+    from voitta_rag_amd import SearchFilter
+
+    rng = np.random.default_rng(dim * 7 + n)
+    x = _corpus(rng, n, dim)
+    x[100:140] = x[100] + rng.standard_normal((40, dim)).astype(np.float32) * 1e-3  # a tight cluster
+    x[200] = x[300]  # exact duplicates -> exact score ties
+    folder = rng.integers(0, 5, size=n).astype(np.int32)
+    e = _engine(dim)
+    e1 = _engine(dim, prefilter=False)
+    for a in range(0, n, 3333):
+        e.upsert(x[a:a + 3333], folder_ids=folder[a:a + 3333])
+        e1.upsert(x[a:a + 3333], folder_ids=folder[a:a + 3333])
+    xh = ocore.cosine_preprocess(x)
+    q = rng.standard_normal((12, dim)).astype(np.float32)
+    q[0] = x[100]       # lands in the cluster: many candidates
+    q[1] = x[300]       # ties
+    q[2] = 0.0          # zero query
+    q[3] *= 1e-4
+    live = np.ones(n, bool)
+    for round_ in range(2):
+        for i in range(q.shape[0]):
+            sc = ocore.dense_scores(ocore.cosine_preprocess(q[i:i + 1]), xh)[0]
+            for k, flt, mask in ((10, None, live), (30, None, live), (64, None, live),
+                                 (10, SearchFilter(include_folders=[1, 3]), live & np.isin(folder, [1, 3]))):
+                wr, ws = ocore.topk(sc, k, mask.astype(np.uint8))
+                for eng in (e, e1):
+                    gr, gs = eng.search_dense(q[i:i + 1], k, flt)[0]
+                    assert np.array_equal(gr, wr), (dim, n, i, k, eng is e)
+                    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        dead = rng.choice(n, size=n // 5, replace=False)
+        e.delete_rows(dead)
+        e1.delete_rows(dead)
+        live[dead] = False
+    st = e.stats()
+    assert st["two_stage"] >= 80 and e1.stats()["two_stage"] == 0
+    print(f"dim {dim} n {n}: two-stage searches {st['two_stage']}, overflow fallbacks {st['fallback']}, "
+          f"last candidate count {st['last_candidates']}")
+    e.close()
+    e1.close()
+
+
+def test_two_stage_overflow_falls_back_to_exact_scan(gpu):
+    """A corpus of near-duplicates cannot be separated by the f16 bounds: every row is a candidate,
+    the re-score budget overflows and the search must transparently redo the one-stage scan."""
+    dim, n = 128, 12000
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal(dim).astype(np.float32)
+    x = (base[None, :] + rng.standard_normal((n, dim)).astype(np.float32) * 2e-4).astype(np.float32)
+    e = _engine(dim)
+    e.upsert(x)
+    xh = ocore.cosine_preprocess(x)
+    q = base + rng.standard_normal(dim).astype(np.float32) * 1e-4
+    sc = ocore.dense_scores(ocore.cosine_preprocess(q[None]), xh)[0]
+    wr, ws = ocore.topk(sc, 10)
+    gr, gs = e.search_dense(q[None], 10)[0]
+    assert np.array_equal(gr, wr) and np.array_equal(gs, ws)
+    st = e.stats()
+    assert st["two_stage"] == 1 and st["fallback"] == 1 and st["last_candidates"] > 4096
+    e.close()

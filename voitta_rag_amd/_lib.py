@@ -20,7 +20,7 @@ class VrConfig(C.Structure):
         ("struct_size", C.c_int32),
         ("device", C.c_int32),
         ("dim", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("flags", C.c_int32),
         ("initial_rows", C.c_int64),
     ]
 
@@ -95,6 +95,7 @@ SIGNATURES = {
                                  _i32p, _i32p, _i64p, _i64p, _i64p]),
     "vr_upsert": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _i32p, _i32p, _i64p, _i64p, _i64p]),
     "vr_delete_rows": (C.c_int, [_vp, _i64p, C.c_int64]),
+    "vr_stats": (C.c_int, [_vp, C.c_int32, _i64p]),
     "vr_count": (C.c_int, [_vp, _i64p, _i64p]),
     "vr_get_dense": (C.c_int, [_vp, _i64p, C.c_int64, _fp]),
     "vr_sparse_stats": (C.c_int, [_vp, _i32p, C.c_int32, _i32p, _i64p]),

@@ -34,6 +34,10 @@ static int ensure_rows(vr_engine* e, int64_t need) {
   const int64_t keep_rows = e->n_rows;
   const int64_t keep_tiles = (keep_rows + kTileRows - 1) / kTileRows;
   VR_TRY(e->corpus.grow(ncap * e->dim, keep_tiles * kTileRows * e->dim, e->stream));
+  if (e->prefilter) {
+    VR_TRY(e->corpus16.grow(ncap * e->dim, keep_tiles * kTileRows * e->dim, e->stream));
+    VR_TRY(e->row_err.grow(ncap, keep_tiles * kTileRows, e->stream));
+  }
   VR_TRY(e->live.grow(ncap, keep_rows, e->stream));
   VR_TRY(e->folder.grow(ncap, keep_rows, e->stream));
   VR_TRY(e->index_folder.grow(ncap, keep_rows, e->stream));
@@ -83,9 +87,17 @@ static const float* stage_query(vr_engine* e, const float* q, int nq, int mem) {
   return pin_dev<float>(e, kPinQuery);
 }
 
-// nq*k keys land in the pinned result area at kPinDenseKeys (readable after a stream sync)
-static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t* mask) {
+// nq*k keys land in the pinned result area at kPinDenseKeys (readable after a stream sync).
+// *two_stage is set when the f16 prefilter path ran: the caller must then check the candidate
+// count at kPinCandCount after the sync and, if it overflowed, call again with allow_prefilter=false.
+static int search_dense_block(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t* mask,
+                              bool allow_prefilter = true, bool* two_stage = nullptr) {
+  if (two_stage) *two_stage = false;
   VR_TRY(dense_make_query_image(e, q_dev, nq));
+  if (allow_prefilter && two_stage && prefilter_usable(e, nq, k)) {
+    *two_stage = true;
+    return prefilter_search(e, k, mask, pin_dev<uint64_t>(e, kPinDenseKeys), pin_dev<int32_t>(e, kPinCandCount));
+  }
   // one or a few queries: scan and selection in one pass, results straight to pinned. A full
   // 16-query block offers 16x the candidates per tile; there the score array + select kernels win.
   if (k <= kFusedMaxK && nq <= 4)
@@ -142,6 +154,7 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
   e->device = cfg->device;
   e->dim = cfg->dim;
   e->kblocks = cfg->dim / kTileK;
+  e->prefilter = (cfg->dim % 32 == 0) && !(cfg->flags & VR_ENGINE_NO_PREFILTER);
   // a blocking stream: it orders itself against the legacy null stream, so device buffers
   // produced by a framework on its default stream are safe to hand in without extra events
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamDefault) != hipSuccess) {
@@ -150,12 +163,18 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
     return -1;
   }
   e->stream = e->own_stream;
+  if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_error("creating the auxiliary stream failed");
+    vr_engine_destroy(e);
+    return -1;
+  }
   if (hipHostMalloc(&e->pinned, kPinnedBytes, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0) != hipSuccess) {
     set_error("hipHostMalloc (mapped) failed");
-    if (e->pinned) (void)hipHostFree(e->pinned);
-    (void)hipStreamDestroy(e->own_stream);
-    delete e;
+    e->pinned = nullptr;
+    vr_engine_destroy(e);
     return -1;
   }
   e->pinned_bytes = kPinnedBytes;
@@ -175,6 +194,11 @@ void vr_engine_destroy(vr_engine* e) {
   encoder_release(e);
   prof_release(e);
   e->corpus.release();
+  e->corpus16.release();
+  e->row_err.release();
+  e->upper.release();
+  e->cand_rows.release();
+  e->cand_keys.release();
   e->live.release();
   e->folder.release();
   e->index_folder.release();
@@ -210,9 +234,13 @@ void vr_engine_destroy(vr_engine* e) {
   e->pass_ifolder.release();
   e->cand_a.release();
   e->cand_b.release();
+  e->sp_cand.release();
   e->q_ids.release();
   e->q_w.release();
   if (e->pinned) (void)hipHostFree(e->pinned);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -276,6 +304,7 @@ static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, c
     x_dev = e->stage_dense.p;
   }
   VR_TRY(dense_store_rows(e, x_dev, n, first));
+  VR_TRY(prefilter_store_rows(e, n, first));  // f16 shadow of the rows just stored (no-op without prefilter)
 
   // payload columns are always host arrays (they come from Python metadata)
   if (folder_id) {
@@ -472,6 +501,18 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n) {
   return 0;
 }
 
+int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
+  VR_CHECK(e != nullptr && out != nullptr, "null argument");
+  std::lock_guard<std::mutex> lock(e->mu);
+  switch (which) {
+    case VR_STAT_TWO_STAGE: *out = e->stat_two_stage; break;
+    case VR_STAT_FALLBACK: *out = e->stat_fallback; break;
+    case VR_STAT_LAST_CANDIDATES: *out = *pin_host<int32_t>(e, kPinCandCount); break;
+    default: set_error("unknown statistic %d", which); return -1;
+  }
+  return 0;
+}
+
 int vr_count(vr_engine* e, int64_t* n_rows, int64_t* n_live) {
   VR_CHECK(e != nullptr, "null engine");
   std::lock_guard<std::mutex> lock(e->mu);
@@ -535,8 +576,16 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
   for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
     const int nb = std::min(kQueryBlock, nq - q0);
     const float* q_dev = stage_query(e, q + static_cast<int64_t>(q0) * e->dim, nb, mem);
-    VR_TRY(search_dense_block(e, q_dev, nb, k, mask));
+    bool two_stage = false;
+    VR_TRY(search_dense_block(e, q_dev, nb, k, mask, true, &two_stage));
     VR_HIP(hipStreamSynchronize(e->stream));
+    e->stat_two_stage += two_stage;
+    if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
+      // more candidates than the re-score budget (near-duplicate corpus): one-stage exact scan
+      ++e->stat_fallback;
+      VR_TRY(search_dense_block(e, q_dev, nb, k, mask, false));
+      VR_HIP(hipStreamSynchronize(e->stream));
+    }
     for (int i = 0; i < nb; ++i) {
       int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k,
                               rows + static_cast<int64_t>(q0 + i) * k,
@@ -587,13 +636,36 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   VR_TRY(filter_build_mask(e, filter, &mask));
   const uint64_t* dense_keys = pin_host<uint64_t>(e, kPinDenseKeys);
   const uint64_t* sparse_keys = pin_host<uint64_t>(e, kPinSparseKeys);
-  VR_TRY(search_dense_block(e, stage_query(e, q, 1, mem), 1, k, mask));
+  const float* q_dev = stage_query(e, q, 1, mem);
+  bool two_stage = false;
   const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
-  if (have_sparse) {
-    VR_CHECK(q_idx && q_val, "null sparse query");
+  // The two legs share nothing but the mask: the (small, latency-bound) sparse leg is forked onto
+  // the auxiliary stream and runs under the dense scan. The k > kFusedMaxK sparse path borrows the
+  // dense leg's selection buffers and stays on the main stream.
+  const bool fork = have_sparse && k <= kFusedMaxK;
+  if (have_sparse) VR_CHECK(q_idx && q_val, "null sparse query");
+  if (fork) VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask, before the dense leg
+  VR_TRY(search_dense_block(e, q_dev, 1, k, mask, true, &two_stage));
+  if (fork) {
+    // queued after the dense leg (whose scan is already running by now), executed beside it
+    VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+    hipStream_t main_stream = e->stream;
+    e->stream = e->aux_stream;
+    const int rc = search_sparse_block(e, q_idx, q_val, nnz, k, mask, false);
+    e->stream = main_stream;
+    if (rc != 0) return rc;
+    VR_HIP(hipEventRecord(e->ev_join, e->aux_stream));
+    VR_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  } else if (have_sparse) {
     VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, false));
   }
   VR_HIP(hipStreamSynchronize(e->stream));
+  e->stat_two_stage += two_stage;
+  if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
+    ++e->stat_fallback;
+    VR_TRY(search_dense_block(e, q_dev, 1, k, mask, false));  // candidate overflow: one-stage exact scan
+    VR_HIP(hipStreamSynchronize(e->stream));
+  }
   int64_t d_rows[kMaxK], s_rows[kMaxK];
   float d_scores[kMaxK], s_scores[kMaxK];
   int nd = static_cast<int>(decode_keys(dense_keys, k, d_rows, d_scores));

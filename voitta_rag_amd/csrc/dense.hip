@@ -104,14 +104,21 @@ int dense_store_rows(vr_engine* e, const float* x_dev, int64_t n, int64_t first_
 // instead of a dependent chain of global loads), then write the whole tiled image.
 __global__ __launch_bounds__(256) void query_image_kernel(const float* __restrict__ q, int nq, int dim,
                                                           int kblocks, float* __restrict__ image) {
-  extern __shared__ float q_raw[];  // [nq][dim]
+  extern __shared__ __align__(16) float q_raw[];  // [nq][dim]
   __shared__ float len[kQueryBlock];
   for (int i = threadIdx.x; i < nq * dim; i += 256) q_raw[i] = q[i];
   __syncthreads();
   if (static_cast<int>(threadIdx.x) < nq) {
-    const float* p = q_raw + threadIdx.x * dim;
+    const float4* p = reinterpret_cast<const float4*>(q_raw + threadIdx.x * dim);  // dim % 16 == 0
     float acc = 0.0f;
-    for (int k = 0; k < dim; ++k) acc = __fadd_rn(acc, __fmul_rn(p[k], p[k]));
+#pragma unroll 8
+    for (int k = 0; k < dim / 4; ++k) {  // wide LDS reads; the additions stay one chain in k order
+      const float4 v = p[k];
+      acc = __fadd_rn(acc, __fmul_rn(v.x, v.x));
+      acc = __fadd_rn(acc, __fmul_rn(v.y, v.y));
+      acc = __fadd_rn(acc, __fmul_rn(v.z, v.z));
+      acc = __fadd_rn(acc, __fmul_rn(v.w, v.w));
+    }
     const bool keep = (acc < FLT_EPSILON) || (fabsf(__fadd_rn(acc, -1.0f)) <= 1.0e-6f);
     len[threadIdx.x] = keep ? 0.0f : __fsqrt_rn(acc);
   }

@@ -97,7 +97,9 @@ constexpr size_t kPinSparseVals = 1024;        // float[kMaxQueryTerms]
 constexpr size_t kPinQuery = 8192;             // float[16][dim <= 1024]
 constexpr size_t kPinDenseKeys = 128 * 1024;   // uint64[16][kMaxK]
 constexpr size_t kPinSparseKeys = 192 * 1024;  // uint64[kMaxK]
+constexpr size_t kPinCandCount = 256 * 1024;   // int32: candidates of the last two-stage dense search
 constexpr size_t kPinnedBytes = 1 << 20;
+constexpr int kMaxCandidates = 4096;           // re-score budget of the two-stage dense search
 
 }  // namespace vr
 
@@ -107,6 +109,10 @@ struct vr_engine {
   int kblocks = 0;  // dim / 16
   hipStream_t stream = nullptr;      // stream every kernel of a call is queued on
   hipStream_t own_stream = nullptr;  // created by the engine; `stream` points here unless rebound
+  // hybrid search runs its sparse leg here, concurrently with the dense leg (fork/join by events)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_join = nullptr;
   std::mutex mu;
 
   int64_t n_rows = 0;
@@ -115,6 +121,17 @@ struct vr_engine {
 
   // dense corpus, MFMA-tiled: [row/16][k/16][lane = (k%4)*16 + row%16][c = (k%16)/4]
   vr::DevArray<float> corpus;
+  // f16 shadow of the corpus for the two-stage exact search (dense8.hip), present when dim % 32 == 0
+  // and not disabled: [row/16][k/32][lane = (k%32)/8*16 + row%16][8 halfs], plus the exact
+  // rounding residual |x - f16(x)|_2 of every row.
+  bool prefilter = false;
+  int64_t stat_two_stage = 0;   // single-query dense searches served by the two-stage path
+  int64_t stat_fallback = 0;    // ... of which overflowed the re-score budget and were redone one-stage
+  vr::DevArray<uint16_t> corpus16;
+  vr::DevArray<float> row_err;
+  vr::DevArray<float> upper;       // [cap_rows] upper bounds of the last prefilter pass
+  vr::DevArray<int32_t> cand_rows; // candidate rows (+ counter at the end)
+  vr::DevArray<uint64_t> cand_keys;
   vr::DevArray<uint8_t> live;
   vr::DevArray<int32_t> folder;
   vr::DevArray<int32_t> index_folder;
@@ -164,6 +181,7 @@ struct vr_engine {
   vr::DevArray<uint8_t> pass_ifolder;
   vr::DevArray<uint64_t> cand_a;
   vr::DevArray<uint64_t> cand_b;
+  vr::DevArray<uint64_t> sp_cand;  // per-block lists of the fused sparse scan
   vr::DevArray<int32_t> q_ids;
   vr::DevArray<float> q_w;
   // Pinned, device-mapped host scratch (1 MiB). Query inputs are written here by the host and
@@ -195,6 +213,11 @@ int dense_make_query_image(vr_engine* e, const float* q_dev, int nq);
 int dense_scores(vr_engine* e, int nq, const uint8_t* mask_dev);
 int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out_dev);
 
+// ---- dense8.hip: f16 prefilter + exact re-score (two-stage exact search)
+int prefilter_store_rows(vr_engine* e, int64_t n, int64_t first_row);
+bool prefilter_usable(vr_engine* e, int nq, int k);
+int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev, int32_t* out_count_dev);
+
 // ---- topk.hip
 // scores: [nq][stride] f32 with -inf / masked rows excluded; result keys (descending) for each
 // query are left in *out_keys (device, [nq][k]).
@@ -203,7 +226,7 @@ int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, in
 // cand: [nq][n_lists][64] keys, every list sorted descending and zero padded (written by the
 // fused scan kernels); writes the k best of every query to out ([nq][k], descending; device-
 // visible memory, normally the pinned result area so that no copy follows).
-int topk_merge_lists(vr_engine* e, const uint64_t* cand, int n_lists, int nq, int k, uint64_t* out);
+int topk_merge_lists(vr_engine* e, uint64_t* cand, int n_lists, int nq, int k, uint64_t* out);  // clobbers cand
 // fused scan + selection, k <= kFusedMaxK; results to out_keys_dev as above
 int dense_scan_topk(vr_engine* e, int nq, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev);
 int sparse_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, int k,

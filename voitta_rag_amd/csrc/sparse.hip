@@ -333,16 +333,16 @@ static int sparse_run(vr_engine* e, const int32_t* q_idx_host, const float* q_va
   if (fused_k) {
     int64_t blocks = std::min<int64_t>((e->n_slices_dev + kSparseWaves - 1) / kSparseWaves, kScanBlocks);
     if (blocks < 1) blocks = 1;
-    VR_TRY(e->cand_a.grow(blocks * kListLen, 0, e->stream));
+    VR_TRY(e->sp_cand.grow(blocks * kListLen, 0, e->stream));  // own buffer: may overlap a dense search
     // algorithmic bytes: every stored id once (4 B) and one mask byte per row
     prof_begin(e, VR_PROF_SPARSE_SCAN, 4.0 * static_cast<double>(e->sp_used) + static_cast<double>(e->n_rows));
     hipLaunchKernelGGL((sparse_scores_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(kSparseWaves * 64),
                        0, e->stream, e->slices.p, e->n_slices_dev, e->sp_idx.p, e->sp_val.p, did, dval, nnz,
                        weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev,
-                       static_cast<float*>(nullptr), fused_k, e->cand_a.p);
+                       static_cast<float*>(nullptr), fused_k, e->sp_cand.p);
     prof_end(e);
     VR_HIP(hipGetLastError());
-    return topk_merge_lists(e, e->cand_a.p, static_cast<int>(blocks), 1, fused_k, out_keys_dev);
+    return topk_merge_lists(e, e->sp_cand.p, static_cast<int>(blocks), 1, fused_k, out_keys_dev);
   }
   VR_TRY(e->sp_scores.grow(e->cap_rows, 0, e->stream));
   VR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->sp_scores.p), 0xFF800000u,

@@ -76,12 +76,15 @@ class SearchFilter:
 class Engine:
     """One HBM-resident index on one GPU."""
 
-    def __init__(self, dim: int, device: int = 0, initial_rows: int = 0):
+    def __init__(self, dim: int, device: int = 0, initial_rows: int = 0, prefilter: bool = True):
+        """prefilter: keep the f16 shadow corpus and run single-query dense searches in two
+        stages (f16 scan + exact re-score; identical results, half of the bytes)."""
         self._lib = _lib.load_library()
         cfg = _lib.VrConfig()
         cfg.struct_size = C.sizeof(_lib.VrConfig)
         cfg.device = device
         cfg.dim = dim
+        cfg.flags = 0 if prefilter else 1  # VR_ENGINE_NO_PREFILTER
         cfg.initial_rows = initial_rows
         h = C.c_void_p()
         check(self._lib.vr_engine_create(C.byref(cfg), C.byref(h)))
@@ -247,6 +250,15 @@ class Engine:
     def delete_rows(self, rows) -> None:
         r = _np(rows, np.int64)
         check(self._lib.vr_delete_rows(self._h, _ptr(r, C.c_int64), r.shape[0]))
+
+    def stats(self) -> dict:
+        """Counters of the two-stage dense search: searches served, overflow fallbacks, last candidate count."""
+        out = {}
+        for name, which in (("two_stage", 0), ("fallback", 1), ("last_candidates", 2)):
+            v = C.c_int64()
+            check(self._lib.vr_stats(self._h, which, C.byref(v)))
+            out[name] = int(v.value)
+        return out
 
     def count(self) -> tuple[int, int]:
         a, b = C.c_int64(), C.c_int64()
