@@ -390,13 +390,16 @@ def main():
                 "share_of_step_time": round(gemm_ms * 1e-3 / dt, 4),
             },
             "roofline_search": {
-                "kernel": "vr::dense_scores_kernel (v_mfma_f32_16x16x4_f32 streaming scan)",
+                "kernel": "vr::prefilter_scan_kernel (v_mfma_f32_16x16x32_f16 streaming scan of the f16 shadow "
+                          "corpus, stage 1 of the exact two-stage search; timed with the sparse leg running "
+                          "beside it on the second stream)",
                 "bound": "hbm",
                 "achieved": round(scan_gbps, 1),
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": round(scan_gbps / PEAK_HBM_GBPS, 4),
-                "traffic": pmc_traffic("dense_scores_kernel"),
+                "traffic": pmc_traffic("prefilter_scan_kernel"),
+                "two_stage": engine.stats(),
                 "algorithmic_bytes_per_launch": round(scan_bytes / max(scan_n, 1)),
                 "launches": scan_n,
                 "avg_launch_ms": round(scan_ms / max(scan_n, 1), 4),
