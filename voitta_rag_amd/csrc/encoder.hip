@@ -82,6 +82,14 @@ struct half2_t {
   half_t x, y;
 };
 
+// Split (hi, lo) matrices live in ONE interleaved array: row r of a [rows][K] matrix is 2K halfs,
+// element k's hi at  r*2K + (k/8)*16 + k%8  and its lo 8 halfs further. A 128-byte line then holds
+// 32 consecutive k of BOTH halves of one row — exactly what a 32-deep GEMM K-tile needs of that row,
+// so the GEMM's global->LDS loads consume every line they touch (with separate hi and lo arrays a
+// 32-deep K-tile used 64 bytes of each line and the L1 fetched every line twice).
+// Callers pass hi = base and lo = base + 8; split_at() turns a column into the offset inside a row.
+__host__ __device__ __forceinline__ int split_at(int k) { return ((k >> 3) << 4) + (k & 7); }
+
 // LayerNorm of one row held as float2 pairs per lane (biased variance, eps inside the sqrt).
 // out_hi/out_lo (optional): the same row split for the f16x3 GEMMs.
 __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs, int H,
@@ -117,8 +125,8 @@ __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs,
         half2_t h, l;
         split_f16(o.x, h.x, l.x);
         split_f16(o.y, h.y, l.y);
-        *reinterpret_cast<half2_t*>(out_hi + e) = h;
-        *reinterpret_cast<half2_t*>(out_lo + e) = l;
+        *reinterpret_cast<half2_t*>(out_hi + split_at(e)) = h;
+        *reinterpret_cast<half2_t*>(out_lo + split_at(e)) = l;
       }
     }
 }
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       v[i].y = w.y + pp.y + tt.y;
     }
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + o : nullptr, x_lo ? x_lo + o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + 2 * o : nullptr, x_lo ? x_lo + 2 * o : nullptr);
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int T, int H,
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < kMaxPairs; ++i)
     if (i < pairs) v[i] = *reinterpret_cast<const float2*>(in + static_cast<int64_t>(t) * H + (i * 64 + lane) * 2);
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + o : nullptr, out_lo ? out_lo + o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + 2 * o : nullptr, out_lo ? out_lo + 2 * o : nullptr);
 }
 
 // one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
@@ -431,19 +439,20 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
   const int lcol = (tid & 7) * 8;
   const int last = M - 1;
   // (named registers, not arrays: arrays indexed inside macros ended up in scratch memory)
-  const int64_t a_off0 = static_cast<int64_t>(min(bm + lrow, last)) * K + lcol;
-  const int64_t a_off1 = static_cast<int64_t>(min(bm + lrow + 32, last)) * K + lcol;
-  const int64_t a_off2 = static_cast<int64_t>(min(bm + lrow + 64, last)) * K + lcol;
-  const int64_t a_off3 = static_cast<int64_t>(min(bm + lrow + 96, last)) * K + lcol;
-  const int64_t w_off0 = static_cast<int64_t>(bn + lrow) * K + lcol;
-  const int64_t w_step = static_cast<int64_t>(32) * K;
+  // (interleaved (hi, lo) rows of 2K halfs, see split_at: 8 halfs of k sit 16 apart)
+  const int64_t a_off0 = static_cast<int64_t>(min(bm + lrow, last)) * (2 * K) + 2 * lcol;
+  const int64_t a_off1 = static_cast<int64_t>(min(bm + lrow + 32, last)) * (2 * K) + 2 * lcol;
+  const int64_t a_off2 = static_cast<int64_t>(min(bm + lrow + 64, last)) * (2 * K) + 2 * lcol;
+  const int64_t a_off3 = static_cast<int64_t>(min(bm + lrow + 96, last)) * (2 * K) + 2 * lcol;
+  const int64_t w_off0 = static_cast<int64_t>(bn + lrow) * (2 * K) + 2 * lcol;
+  const int64_t w_step = static_cast<int64_t>(32) * (2 * K);
   uint4 r_ah0, r_ah1, r_ah2, r_ah3, r_al0, r_al1, r_al2, r_al3;
   uint4 r_wh0, r_wh1, r_wh2, r_wh3, r_wl0, r_wl1, r_wl2, r_wl3;
 #define VR_HLOAD1(P, k0)                                                              \
-  r_ah##P = *reinterpret_cast<const uint4*>(Ah + a_off##P + (k0));                    \
-  r_al##P = *reinterpret_cast<const uint4*>(Al + a_off##P + (k0));                    \
-  r_wh##P = *reinterpret_cast<const uint4*>(Wh + w_off0 + P * w_step + (k0));         \
-  r_wl##P = *reinterpret_cast<const uint4*>(Wl + w_off0 + P * w_step + (k0));
+  r_ah##P = *reinterpret_cast<const uint4*>(Ah + a_off##P + 2 * (k0));                \
+  r_al##P = *reinterpret_cast<const uint4*>(Al + a_off##P + 2 * (k0));                \
+  r_wh##P = *reinterpret_cast<const uint4*>(Wh + w_off0 + P * w_step + 2 * (k0));     \
+  r_wl##P = *reinterpret_cast<const uint4*>(Wl + w_off0 + P * w_step + 2 * (k0));
 #define VR_HLOAD(k0) \
   do {               \
     VR_HLOAD1(0, k0) VR_HLOAD1(1, k0) VR_HLOAD1(2, k0) VR_HLOAD1(3, k0) \
@@ -545,8 +554,9 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
         g[c] = 0.5f * g[c] * (1.0f + erff(g[c] * 0.70710678118654752440f));
         split_f16(g[c], h[c], l[c]);
       }
-      *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
-      *reinterpret_cast<uint2*>(Cl + o) = *reinterpret_cast<const uint2*>(l);
+      const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
+      *reinterpret_cast<uint2*>(Ch + so) = *reinterpret_cast<const uint2*>(h);
+      *reinterpret_cast<uint2*>(Cl + so) = *reinterpret_cast<const uint2*>(l);
     } else {
       if (EPI == EPI_BIAS_RESIDUAL) {
         const float4 r4 = *reinterpret_cast<const float4*>(R + o);
@@ -557,6 +567,231 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
       }
       *reinterpret_cast<float4*>(C + o) = v;
     }
+  }
+}
+
+// ---- the same product on a 256x256 block tile -----------------------------------------------------
+//
+// 8 waves as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA tiles: per 16-deep k-step a wave reads 12
+// fragments (8 of A, 4 of W; hi and lo) for 24 MFMAs — half the LDS bytes per MFMA of the 128x128
+// kernel above, whose LDS pipe was as busy as its matrix pipe. One block per CU (128 KiB of LDS):
+// two 64-KiB stages [A, W][256 rows][128 B = 32 k of hi and lo], filled by global_load_lds_dwordx4 (no
+// staging registers, no ds_write pass) for K-tile t+1 while K-tile t is multiplied; one barrier per
+// K-tile. A direct-to-LDS load writes wave-uniform base + lane*16, so the image is unpadded; bank
+// conflicts are avoided by an XOR swizzle applied on the SOURCE side: LDS chunk p of row r holds
+// the row's 16-byte chunk p ^ ((r >> 1) & 7), and fragment reads use the same permutation (every
+// lane group of a ds_read_b128 then covers all 64 banks once).
+
+constexpr int GBM = 256, GBN = 256, GBK = 32;
+constexpr int kStageHalfs = 4 * 256 * GBK;  // 64 KiB
+constexpr int kGroupM256 = 4;
+
+__device__ __forceinline__ void glds16(const half_t* src, half_t* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
+    const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
+    const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
+    float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
+    float unscale, long long* __restrict__ stamps) {
+  __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object of the kernel (a second one makes hipcc
+                                           // drain the in-flight loads before every fragment read)
+  const int tiles_n = N / GBN;
+  const int tiles_m = (M + GBM - 1) / GBM;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+  int tm, tn;
+  {
+    const int per_group = kGroupM256 * tiles_n;
+    const int group = swz / per_group;
+    const int within = swz - group * per_group;
+    const int gm = min(kGroupM256, tiles_m - group * kGroupM256);
+    tm = group * kGroupM256 + within % gm;
+    tn = within / gm;
+  }
+  const int bm = tm * GBM;
+  const int bn = tn * GBN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // staging: a direct-to-LDS load moves 8 rows x 128 B (one line per row: 32 k of hi and lo, see
+  // split_at). Wave w fills row groups w, w + 8, w + 16, w + 24 of the A image and of the W image;
+  // lane -> row (lane >> 3) of the group, LDS chunk (lane & 7), source chunk (lane & 7) ^ ((row >> 1) & 7).
+  const int srow = lane >> 3;
+  const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  const int r0 = wave * 8 + srow;  // + 64 j
+  const int64_t K2 = 2 * static_cast<int64_t>(K);
+  const half_t* g_a0 = Ah + static_cast<int64_t>(min(bm + r0, M - 1)) * K2 + schunk;
+  const half_t* g_a1 = Ah + static_cast<int64_t>(min(bm + r0 + 64, M - 1)) * K2 + schunk;
+  const half_t* g_a2 = Ah + static_cast<int64_t>(min(bm + r0 + 128, M - 1)) * K2 + schunk;
+  const half_t* g_a3 = Ah + static_cast<int64_t>(min(bm + r0 + 192, M - 1)) * K2 + schunk;
+  const half_t* g_w0 = Wh + static_cast<int64_t>(bn + r0) * K2 + schunk;
+  const half_t* g_w1 = Wh + static_cast<int64_t>(bn + r0 + 64) * K2 + schunk;
+  const half_t* g_w2 = Wh + static_cast<int64_t>(bn + r0 + 128) * K2 + schunk;
+  const half_t* g_w3 = Wh + static_cast<int64_t>(bn + r0 + 192) * K2 + schunk;
+  half_t* l_dst = lds + wave * 8 * 64;  // rows of 64 halfs (128 B); the W image starts at 256 * 64
+#define VR_GLDS_STAGE(buf, k0)                                          \
+  do {                                                                  \
+    half_t* d = l_dst + (buf) * kStageHalfs;                            \
+    glds16(g_a0 + 2 * (k0), d);                                         \
+    glds16(g_a1 + 2 * (k0), d + 64 * 64);                               \
+    glds16(g_a2 + 2 * (k0), d + 128 * 64);                              \
+    glds16(g_a3 + 2 * (k0), d + 192 * 64);                              \
+    glds16(g_w0 + 2 * (k0), d + 256 * 64);                              \
+    glds16(g_w1 + 2 * (k0), d + 256 * 64 + 64 * 64);                    \
+    glds16(g_w2 + 2 * (k0), d + 256 * 64 + 128 * 64);                   \
+    glds16(g_w3 + 2 * (k0), d + 256 * 64 + 192 * 64);                   \
+  } while (0)
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // fragments: lane l supplies row (l & 31), k = 8*(l >> 5) + j of a 16-deep step: k8-group
+  // g = 2*kk + (l >> 5), whose hi is chunk 2g and lo chunk 2g + 1 of the row's line
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int fh0 = ((2 * (lane >> 5)) ^ fsw) * 8, fl0 = ((2 * (lane >> 5) + 1) ^ fsw) * 8;          // k-step 0
+  const int fh1 = ((2 * (2 + (lane >> 5))) ^ fsw) * 8, fl1 = ((2 * (2 + (lane >> 5)) + 1) ^ fsw) * 8;  // k-step 1
+  const int pa = (wm * 128 + frow) * 64;
+  const int pw = 256 * 64 + (wn * 64 + frow) * 64;
+
+  const int nk = K / GBK;
+  long long t_start = 0, t_loop = 0, t_epi = 0;
+  if (stamps) t_start = __builtin_amdgcn_s_memtime();
+  VR_GLDS_STAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stamps) t_loop = __builtin_amdgcn_s_memtime();
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* st = lds + (kt & 1) * kStageHalfs;
+    // A direct-to-LDS load holds the issuing wave for ~100+ cycles. Eight of them in a row at the top
+    // of the K-tile left the matrix pipe idle for a third of it; instead one load is issued after
+    // every six MFMAs (one row of MFMA tiles), where the partner wave of the SIMD fills the gap.
+    // (the last K-tile re-loads tile 0 into the idle stage instead of branching around every load:
+    //  nothing reads it, and the vmcnt(0) + barrier below retire it before the epilogue reuses LDS)
+    half_t* nd = l_dst + ((kt + 1) & 1) * kStageHalfs;
+    const int nk0 = kt + 1 < nk ? 2 * (kt + 1) * GBK : 0;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fh = kk ? fh1 : fh0, fl = kk ? fl1 : fl0;
+      f16x8 ah[4], al[4], wh[2], wl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
+        wl[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fl);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
+        al[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fl);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+        }
+        {
+          const int piece = kk * 4 + i;  // compile-time after unrolling
+          const half_t* src = piece == 0 ? g_a0 : piece == 1 ? g_a1 : piece == 2 ? g_a2 : piece == 3 ? g_a3
+                            : piece == 4 ? g_w0 : piece == 5 ? g_w1 : piece == 6 ? g_w2 : g_w3;
+          glds16(src + nk0, nd + (piece >> 2) * 256 * 64 + (piece & 3) * 64 * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the load where it was written, between the MFMA rows
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K-tile kt+1 have landed
+    __syncthreads();                                   // ... everybody's have, and K-tile kt is consumed
+  }
+#undef VR_GLDS_STAGE
+  if (stamps) t_epi = __builtin_amdgcn_s_memtime();
+
+  // Epilogue through LDS, one 32-row tile of the wave at a time (see gemm_f16x3_kernel): the wave
+  // parks 32x64 accumulators in its own region and reads them back by rows for 16-byte accesses.
+  // The residual rows of a tile are requested BEFORE its accumulators are parked, all eight loads at
+  // once: read one by one inside the store loop they cost eight exposed HBM latencies per tile.
+  constexpr int SLD = 64 + 4;
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SLD);
+  const int c4 = (lane & 15) * 4;
+  const int gcol = bn + wn * 64 + c4;
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + gcol);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row0 = bm + wm * 128 + i * 32 + (lane >> 4);  // + 4 * it
+    float4 r4[8];
+    if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        r4[it] = *reinterpret_cast<const float4*>(R + static_cast<int64_t>(min(row0 + 4 * it, M - 1)) * N + gcol);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    auto emit = [&](int it) {
+      const int lr = it * 4 + (lane >> 4);
+      const int grow = row0 + 4 * it;
+      float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
+      if (grow >= M) return;
+      v.x = v.x * unscale + b4.x;
+      v.y = v.y * unscale + b4.y;
+      v.z = v.z * unscale + b4.z;
+      v.w = v.w * unscale + b4.w;
+      const int64_t o = static_cast<int64_t>(grow) * N + gcol;
+      if (EPI == EPI_BIAS_GELU) {
+        float g[4] = {v.x, v.y, v.z, v.w};
+        half_t h[4], l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          g[c] = 0.5f * g[c] * (1.0f + erff(g[c] * 0.70710678118654752440f));
+          split_f16(g[c], h[c], l[c]);
+        }
+        const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
+        *reinterpret_cast<uint2*>(Ch + so) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(Cl + so) = *reinterpret_cast<const uint2*>(l);
+      } else {
+        if (EPI == EPI_BIAS_RESIDUAL) {
+          v.x += r4[it].x;
+          v.y += r4[it].y;
+          v.z += r4[it].z;
+          v.w += r4[it].w;
+        }
+        *reinterpret_cast<float4*>(C + o) = v;
+      }
+    };
+    if constexpr (EPI == EPI_BIAS_RESIDUAL) {  // r4[] needs compile-time indices
+#pragma unroll
+      for (int it = 0; it < 8; ++it) emit(it);
+    } else {  // four rows at a time: deeper unrolling only lengthened these two epilogues
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) emit(it);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // the rows are read before the next tile overwrites the region
+  }
+  if (stamps && tid == 0) {  // diagnostic build only (VR_GEMM_STAMPS): phase lengths of this block, in shader cycles
+    const long long t_end = __builtin_amdgcn_s_memtime();
+    stamps[blockIdx.x * 4 + 0] = t_loop - t_start;
+    stamps[blockIdx.x * 4 + 1] = t_epi - t_loop;
+    stamps[blockIdx.x * 4 + 2] = t_end - t_epi;
+    stamps[blockIdx.x * 4 + 3] = t_start;
   }
 }
 
@@ -575,14 +810,15 @@ __global__ void absmax_kernel(const float* __restrict__ w, int64_t n, unsigned i
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order as uints
 }
 
-__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, float scale,
+__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int K, float scale,
                                      half_t* __restrict__ hi, half_t* __restrict__ lo) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) {
     half_t h, l;
     split_f16(w[i] * scale, h, l);
-    hi[i] = h;
-    lo[i] = l;
+    const int64_t o = (i / K) * (2 * K) + split_at(static_cast<int>(i % K));  // interleaved layout, see split_at
+    hi[o] = h;
+    lo[o] = l;
   }
 }
 
@@ -592,9 +828,50 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   VR_CHECK(N % HBN_ == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, HBN_, HBK_);
   if (M <= 0) return 0;
   hipStream_t s = e->stream;
-  const int grid = ((M + HBM_ - 1) / HBM_) * (N / HBN_);
   static const int ablate = getenv("VR_GEMM_ABLATE") ? atoi(getenv("VR_GEMM_ABLATE")) : 0;  // timing experiments only
+  static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
+  if (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128) {
+    const int grid256 = ((M + GBM - 1) / GBM) * (N / GBN);
+    static const bool want_stamps = getenv("VR_GEMM_STAMPS") != nullptr;  // diagnostics: phase lengths per block
+    static int stamp_prints = 0;
+    long long* stamps = nullptr;
+    if (want_stamps && stamp_prints < 12) VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), sizeof(long long) * 4 * grid256));
+    switch (epi) {
+      case EPI_BIAS:
+        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R,
+                           C, Ch, Cl, M, N, K, unscale, stamps);
+        break;
+      case EPI_BIAS_GELU:
+        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_GELU>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl,
+                           bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+        break;
+      default:
+        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_RESIDUAL>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl,
+                           bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+        break;
+    }
+    prof_end(e);
+    if (stamps) {
+      std::vector<long long> h(static_cast<size_t>(4) * grid256);
+      VR_HIP(hipStreamSynchronize(s));
+      VR_HIP(hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      (void)hipFree(stamps);
+      double p = 0, l = 0, ep = 0;
+      long long t0 = h[3], t1 = h[3];
+      for (int b = 0; b < grid256; ++b) {
+        p += h[4 * b]; l += h[4 * b + 1]; ep += h[4 * b + 2];
+        t0 = std::min(t0, h[4 * b + 3]); t1 = std::max(t1, h[4 * b + 3] + h[4 * b] + h[4 * b + 1] + h[4 * b + 2]);
+      }
+      fprintf(stderr, "[gemm256 epi=%d M=%d N=%d K=%d] blocks %d: prologue %.0f  loop %.0f (%.0f / K-tile)  epilogue %.0f cycles; "
+              "kernel span %lld cycles\n", epi, M, N, K, grid256, p / grid256, l / grid256, l / grid256 / (K / GBK), ep / grid256,
+              t1 - t0);
+      ++stamp_prints;
+    }
+    VR_HIP(hipGetLastError());
+    return 0;
+  }
+  const int grid = ((M + HBM_ - 1) / HBM_) * (N / HBN_);
   switch (epi) {
     case EPI_BIAS:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R, C, Ch,
@@ -736,8 +1013,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         split_f16(v.y, h[1], lo[1]);
         split_f16(v.z, h[2], lo[2]);
         split_f16(v.w, h[3], lo[3]);
-        *reinterpret_cast<uint2*>(ctx_hi + off + 16 * s) = *reinterpret_cast<const uint2*>(h);
-        *reinterpret_cast<uint2*>(ctx_lo + off + 16 * s) = *reinterpret_cast<const uint2*>(lo);
+        const int64_t so = static_cast<int64_t>(t0 + q_tok) * (2 * H) + split_at(head * DH + 4 * g + 16 * s);
+        *reinterpret_cast<uint2*>(ctx_hi + so) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(ctx_lo + so) = *reinterpret_cast<const uint2*>(lo);
       } else {
         *reinterpret_cast<float4*>(ctx + off + 16 * s) = v;
       }
@@ -759,7 +1037,7 @@ static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_
 }
 
 // w (device, n floats) -> scaled (hi, lo) f16 pair; scale = 2^s puts max|w| into [1024, 2048)
-static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, SplitWeight* out) {
+static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, int K, SplitWeight* out) {
   float* scratch = nullptr;
   VR_TRY(dev_alloc_copy(e, enc, nullptr, 1, 0, &scratch));
   VR_HIP(hipMemsetAsync(scratch, 0, sizeof(float), e->stream));
@@ -778,13 +1056,12 @@ static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, 
   }
   const float scale = std::ldexp(1.0f, s);
   out->unscale = std::ldexp(1.0f, -s);
-  float *hi = nullptr, *lo = nullptr;
-  VR_TRY(dev_alloc_copy(e, enc, nullptr, (n + 1) / 2, 0, &hi));
-  VR_TRY(dev_alloc_copy(e, enc, nullptr, (n + 1) / 2, 0, &lo));
-  out->hi = reinterpret_cast<_Float16*>(hi);
-  out->lo = reinterpret_cast<_Float16*>(lo);
+  float* both = nullptr;  // one interleaved array of 2n halfs (= n floats), see split_at
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, n, 0, &both));
+  out->hi = reinterpret_cast<_Float16*>(both);
+  out->lo = out->hi + 8;
   hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream,
-                     w_dev, static_cast<int64_t>(n), scale, out->hi, out->lo);
+                     w_dev, static_cast<int64_t>(n), K, scale, out->hi, out->lo);
   VR_HIP(hipGetLastError());
   return 0;
 }
@@ -848,10 +1125,10 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
     VR_TRY(dev_alloc_copy(e, enc, w[14], H, mem, &lw.ln2g));
     VR_TRY(dev_alloc_copy(e, enc, w[15], H, mem, &lw.ln2b));
     if (d->precision == VR_PRECISION_F16X3) {
-      VR_TRY(make_split(e, enc, lw.wqkv, 3 * HH, &lw.s_qkv));
-      VR_TRY(make_split(e, enc, lw.wo, HH, &lw.s_o));
-      VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, &lw.s_1));
-      VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, &lw.s_2));
+      VR_TRY(make_split(e, enc, lw.wqkv, 3 * HH, H, &lw.s_qkv));
+      VR_TRY(make_split(e, enc, lw.wo, HH, H, &lw.s_o));
+      VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, H, &lw.s_1));
+      VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, I, &lw.s_2));
     }
     enc->layers.push_back(lw);
   }
@@ -892,13 +1169,12 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   // f16x3 mode: every GEMM input also exists as (hi, lo) f16. The split hidden state lives in xs;
   // the context and the FFN intermediate are ONLY needed split, so they reuse the f32 buffers.
   const bool split = d.precision == VR_PRECISION_F16X3;
-  const int64_t TH = static_cast<int64_t>(T) * H, TI = static_cast<int64_t>(T) * I;
   half_t* xh = split ? reinterpret_cast<half_t*>(enc->xs) : nullptr;
-  half_t* xl = split ? xh + TH : nullptr;
+  half_t* xl = split ? xh + 8 : nullptr;  // interleaved (hi, lo) layout, see split_at
   half_t* ch = split ? reinterpret_cast<half_t*>(enc->ctx) : nullptr;
-  half_t* cl = split ? ch + TH : nullptr;
+  half_t* cl = split ? ch + 8 : nullptr;
   half_t* fh = split ? reinterpret_cast<half_t*>(enc->ffn) : nullptr;
-  half_t* fl = split ? fh + TI : nullptr;
+  half_t* fl = split ? fh + 8 : nullptr;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
                      enc->x, xh, xl);
@@ -944,7 +1220,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   return 0;
 }
 
-constexpr int64_t kMaxChunkTokens = 32768;
+// Tokens per forward pass. Large enough that the 768-wide GEMMs still launch several full rounds of
+// 256x256 tiles (131072 tokens x 768 columns = 1536 tiles on 256 CUs); activations for it are
+// ~45 KB per token (5.9 GB). VR_CHUNK_TOKENS overrides it for experiments.
+static const int64_t kMaxChunkTokens = getenv("VR_CHUNK_TOKENS") ? atoll(getenv("VR_CHUNK_TOKENS")) : 131072;
 
 int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int n_seq, int mem,
                    float* out, int out_mem) {
