@@ -82,6 +82,22 @@ struct half2_t {
   half_t x, y;
 };
 
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) for the f16x3 epilogues, where erff() made the epilogue VALU-bound
+// (a third of the FFN-up tile time). Abramowitz-Stegun 7.1.26: erfc(z) = t (a1 + t (a2 + ... a5 t)) e^{-z^2},
+// t = 1 / (1 + p z), |error| <= 1.5e-7 — the size of an f32 ulp of erf, and far inside what the (hi, lo)
+// split of the result keeps. Negative x uses 0.5 x erfc(|x| / sqrt 2) directly, so the tail has no
+// cancellation. 13 instructions (one v_rcp_f32, one v_exp_f32) against ~40 for erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // erfc(z)
+  return x >= 0.0f ? x * fmaf(-0.5f, q, 1.0f) : 0.5f * x * q;
+}
+
 // Split (hi, lo) matrices live in ONE interleaved array: row r of a [rows][K] matrix is 2K halfs,
 // element k's hi at  r*2K + (k/8)*16 + k%8  and its lo 8 halfs further. A 128-byte line then holds
 // 32 consecutive k of BOTH halves of one row — exactly what a 32-deep GEMM K-tile needs of that row,
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
       half_t h[4], l[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        g[c] = 0.5f * g[c] * (1.0f + erff(g[c] * 0.70710678118654752440f));
+        g[c] = gelu_fast(g[c]);
         split_f16(g[c], h[c], l[c]);
       }
       const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
@@ -722,21 +738,28 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 
   // Epilogue through LDS, one 32-row tile of the wave at a time (see gemm_f16x3_kernel): the wave
   // parks 32x64 accumulators in its own region and reads them back by rows for 16-byte accesses.
-  // The residual rows of a tile are requested BEFORE its accumulators are parked, all eight loads at
-  // once: read one by one inside the store loop they cost eight exposed HBM latencies per tile.
+  // The residual rows of a tile are requested one tile AHEAD, all eight loads at once: read one by
+  // one inside the store loop they cost eight exposed HBM latencies per tile.
   constexpr int SLD = 64 + 4;
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SLD);
   const int c4 = (lane & 15) * 4;
   const int gcol = bn + wn * 64 + c4;
   const float4 b4 = *reinterpret_cast<const float4*>(bias + gcol);
+  float4 r4[2][8];  // residual rows of the current tile and of the next one (requested a tile ahead)
+  if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      r4[0][it] = *reinterpret_cast<const float4*>(
+          R + static_cast<int64_t>(min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1)) * N + gcol);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row0 = bm + wm * 128 + i * 32 + (lane >> 4);  // + 4 * it
-    float4 r4[8];
-    if (EPI == EPI_BIAS_RESIDUAL) {
+    if (EPI == EPI_BIAS_RESIDUAL && i + 1 < 4) {
 #pragma unroll
       for (int it = 0; it < 8; ++it)
-        r4[it] = *reinterpret_cast<const float4*>(R + static_cast<int64_t>(min(row0 + 4 * it, M - 1)) * N + gcol);
+        r4[(i + 1) & 1][it] = *reinterpret_cast<const float4*>(
+            R + static_cast<int64_t>(min(row0 + 32 + 4 * it, M - 1)) * N + gcol);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -760,7 +783,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
         half_t h[4], l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          g[c] = 0.5f * g[c] * (1.0f + erff(g[c] * 0.70710678118654752440f));
+          g[c] = gelu_fast(g[c]);
           split_f16(g[c], h[c], l[c]);
         }
         const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
@@ -768,10 +791,10 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
         *reinterpret_cast<uint2*>(Cl + so) = *reinterpret_cast<const uint2*>(l);
       } else {
         if (EPI == EPI_BIAS_RESIDUAL) {
-          v.x += r4[it].x;
-          v.y += r4[it].y;
-          v.z += r4[it].z;
-          v.w += r4[it].w;
+          v.x += r4[i & 1][it].x;
+          v.y += r4[i & 1][it].y;
+          v.z += r4[i & 1][it].z;
+          v.w += r4[i & 1][it].w;
         }
         *reinterpret_cast<float4*>(C + o) = v;
       }
