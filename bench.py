@@ -375,7 +375,7 @@ def main():
             # three f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOP/s is the dense f16 peak / 3.
             "roofline": {
                 "kernel": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.precision == "f32" else
-                          "vr::gemm_f16x3_kernel (v_mfma_f32_32x32x16_f16, 3 passes per product)",
+                          "vr::gemm_f16x3_256_kernel (v_mfma_f32_32x32x16_f16, 3 passes per product; 256x256 tiles)",
                 "bound": "mfma",
                 "achieved": round(gemm_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else round(PEAK_F16_MFMA_TFLOPS / 3.0, 1),
