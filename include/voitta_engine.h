@@ -264,6 +264,17 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem,
                      const vr_filter* filter,
                      int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
 
+/* Persistence. The reference's index survives a restart in Qdrant's volume
+ * (docker-compose.yml:8-9; VectorStoreService._ensure_collection re-attaches, vector_store.py:75-115).
+ * vr_save writes everything the device owns — tiled dense corpus, payload columns, tombstones,
+ * SELL sparse index, document-frequency table — to ONE file (written to path + ".tmp", then renamed
+ * over `path`); vr_load restores it into an EMPTY engine of the same dimension and rebuilds the
+ * f16 shadow. Row numbers, scores and rankings after a load are identical to those before the
+ * save. The file is checksummed; a truncated or corrupt file is refused. Payload text, point ids
+ * and the folder dictionaries belong to the host (voitta_rag_amd/vector_store.py saves them beside it). */
+int vr_save(vr_engine* e, const char* path);
+int vr_load(vr_engine* e, const char* path);
+
 /* The fusion arithmetic alone (host, no GPU): what vector_store.py:659-697 does to two result
  * lists. Exposed so the reference's own two-list code path can be checked in isolation.
  * json_scores != 0 reproduces the REST transport of the reference (f32 score -> shortest decimal

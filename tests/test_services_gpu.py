@@ -212,3 +212,52 @@ def test_full_flow_like_indexing_service_and_mcp_search(native):
     vs.set_file_acl("d.txt", ["a@b.c"])
     assert all(c.metadata.allowed_users == ["a@b.c"] for c in vs.get_chunks_by_range("d.txt", 0, 99))
     assert vs.get_collection_info()["points_count"] == 23
+
+
+def test_collection_survives_a_restart(native, tmp_path, monkeypatch):
+    """save() -> new process state (registry reset) -> a fresh VectorStoreService finds everything
+    again, like the reference re-attaching to Qdrant's volume (vector_store.py:75-115)."""
+    path, shape, w, vocab = native()
+    from voitta_rag_amd import config, store_registry, vector_store
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import ChunkMetadata, VectorStoreService
+
+    rng = np.random.default_rng(11)
+    emb, sp = get_embedding_service(), get_sparse_embedding_service()
+    vs = VectorStoreService()
+    texts = _texts(rng, 60)
+    metas = [ChunkMetadata(file_path=f"docs/f{i % 3}.md", folder_path="docs", index_folder="docs", file_name=f"f{i % 3}.md",
+                           chunk_index=i // 3, total_chunks=20, start_char=0, end_char=9, indexed_at="2026-01-01T00:00:00",
+                           source_modified_at=1_700_000_000 + i, allowed_users=["ann"] if i % 2 else None)
+             for i in range(len(texts))]
+    ids = vs.store_chunks(list(zip(texts, emb.embed_texts(texts), metas)), sparse_vectors=sp.embed_texts(texts))
+    assert vs.delete_by_file("docs/f1.md") == 20
+    q = emb.embed_query(texts[0])
+    sq = sp.embed_query(texts[0])
+    want = [(c.id, c.score, c.text, c.metadata) for c in vs.search(q, limit=10, sparse_query=sq, sparse_weight=0.2)]
+    want_dense = [(c.id, c.score) for c in vs.search(q, limit=5, folder_filter="docs")]
+    info = vs.get_collection_info()
+    index_dir = str(tmp_path / "persist")
+    assert vs.save(index_dir) == index_dir
+    # "restart": drop the engine and every host table, point VOITTA_INDEX_DIR at the saved files
+    monkeypatch.setenv("VOITTA_INDEX_DIR", index_dir)
+    config.get_settings.cache_clear()
+    store_registry.reset()
+    vector_store._vector_store = None
+    vs2 = VectorStoreService()
+    assert vs2.get_collection_info() == info
+    got = [(c.id, c.score, c.text, c.metadata) for c in vs2.search(q, limit=10, sparse_query=sq, sparse_weight=0.2)]
+    assert got == want
+    assert [(c.id, c.score) for c in vs2.search(q, limit=5, folder_filter="docs")] == want_dense
+    assert vs2.count_by_file("docs/f0.md") == 20 and vs2.count_by_file("docs/f1.md") == 0
+    assert set(ids) >= {c[0] for c in got}
+    # the restored collection keeps accepting writes (the encoder is re-created too: it lived in the old engine)
+    from voitta_rag_amd import embedding, sparse_embedding
+
+    embedding._embedding_service = None
+    sparse_embedding._sparse_embedding_service = None
+    emb2, sp2 = get_embedding_service(), get_sparse_embedding_service()
+    assert np.array_equal(np.asarray(emb2.embed_query(texts[0]), np.float32), np.asarray(q, np.float32))
+    more = vs2.store_chunks(list(zip(texts[:5], emb2.embed_texts(texts[:5]), metas[:5])), sparse_vectors=sp2.embed_texts(texts[:5]))
+    assert len(more) == 5 and vs2.get_collection_info()["points_count"] == info["points_count"] + 5

@@ -19,6 +19,8 @@ class Settings:
         # native additions
         self.gpu: int = int(os.getenv("VOITTA_GPU", os.getenv("LOCAL_RANK", "0")))
         self.initial_rows: int = int(os.getenv("VOITTA_INITIAL_ROWS", "0"))
+        # directory of the persisted index (VectorStoreService.save / load); loaded on first use when present
+        self.index_dir: str = os.getenv("VOITTA_INDEX_DIR", "")
 
 
 @lru_cache

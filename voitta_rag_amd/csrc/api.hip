@@ -26,7 +26,7 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int64_t n) {
   if (i < n) p[i] = v;
 }
 
-static int ensure_rows(vr_engine* e, int64_t need) {
+int ensure_rows(vr_engine* e, int64_t need) {
   if (need <= e->cap_rows) return 0;
   int64_t ncap = e->cap_rows ? e->cap_rows : 1024;
   while (ncap < need) ncap *= 2;
@@ -675,6 +675,20 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
                        out_scores, out_from_dense, out_count);
   return fuse_rrf(d_rows, nd, s_rows, ns, limit, sparse_weight, out_rows, out_scores, out_from_dense,
                   out_count);
+}
+
+int vr_save(vr_engine* e, const char* path) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(path && *path, "null path");
+  std::lock_guard<std::mutex> lock(e->mu);
+  return engine_save(e, path);
+}
+
+int vr_load(vr_engine* e, const char* path) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(path && *path, "null path");
+  std::lock_guard<std::mutex> lock(e->mu);
+  return engine_load(e, path);
 }
 
 int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd, const int64_t* s_rows,

@@ -207,6 +207,13 @@ inline T* pin_dev(vr_engine* e, size_t off) {
   return reinterpret_cast<T*>(static_cast<char*>(e->pinned_dev) + off);
 }
 
+// ---- api.hip
+int ensure_rows(vr_engine* e, int64_t need);  // grow every per-row table to hold `need` rows
+
+// ---- persist.hip: on-disk image of the index (vr_save / vr_load)
+int engine_save(vr_engine* e, const char* path);
+int engine_load(vr_engine* e, const char* path);
+
 // ---- dense.hip
 int dense_store_rows(vr_engine* e, const float* x_dev, int64_t n, int64_t first_row);
 int dense_make_query_image(vr_engine* e, const float* q_dev, int nq);

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(uint64_t* __
   // Keys are unique (they carry the row) apart from the empty key 0.
   {
     uint64_t t = 0;  // one thread per list (n_lists <= kMergeMaxLists <= kMergeThreads)
-    if (threadIdx.x < n_lists) {
+    if (static_cast<int>(threadIdx.x) < n_lists) {
       heads[threadIdx.x] = in[threadIdx.x * kListLen];
       t = in[threadIdx.x * kListLen + (k - 1)];
     }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(uint64_t* __
       head_thr = 0;
     }
     __syncthreads();
-    if (threadIdx.x < n_lists) {
+    if (static_cast<int>(threadIdx.x) < n_lists) {
       const uint64_t h = heads[threadIdx.x];
       int rank = 0;
       for (int j = 0; j < n_lists; ++j) rank += heads[j] > h;

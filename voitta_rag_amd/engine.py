@@ -4,6 +4,7 @@ passed as a device pointer. No arithmetic happens here."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -259,6 +260,15 @@ class Engine:
             check(self._lib.vr_stats(self._h, which, C.byref(v)))
             out[name] = int(v.value)
         return out
+
+    def save(self, path: str) -> None:
+        """Write the device-resident index (dense, sparse, payload columns, tombstones, document
+        frequencies) to one checksummed file; the write is atomic (tmp + rename)."""
+        check(self._lib.vr_save(self._h, os.fsencode(path)))
+
+    def load(self, path: str) -> None:
+        """Restore a file written by save() into this (empty, same-dimension) engine."""
+        check(self._lib.vr_load(self._h, os.fsencode(path)))
 
     def count(self) -> tuple[int, int]:
         a, b = C.c_int64(), C.c_int64()

@@ -9,7 +9,9 @@ get_* helpers swallow exceptions and return 0 / {} / [] / None (vector_store.py:
 894,975,1014)."""
 from __future__ import annotations
 
+import json
 import logging
+import os
 import threading
 import uuid
 from dataclasses import dataclass
@@ -112,8 +114,84 @@ class VectorStoreService:
         return self._client
 
     def _ensure_collection(self) -> None:
-        collection(self.collection_name, _Collection)
+        # The reference re-attaches to whatever the Qdrant volume holds (vector_store.py:75-115,
+        # docker-compose.yml:8-9); here a saved index under VOITTA_INDEX_DIR is loaded once, when the
+        # collection is first bound in this process and the engine is still empty.
+        fresh = []
+
+        def factory():
+            fresh.append(True)
+            return _Collection()
+
+        col = collection(self.collection_name, factory)
+        index_dir = get_settings().index_dir
+        if fresh and index_dir and os.path.exists(self._paths(index_dir)[0]) and self._client.count()[0] == 0:
+            self._load_into(col, index_dir)
         self._has_sparse = True  # every collection is created with the "bm25" sparse vector (:95-99,114)
+
+    # ---- persistence ---------------------------------------------------------
+    def _paths(self, directory: str) -> tuple[str, str, str]:
+        base = os.path.join(directory, self.collection_name)
+        return base + ".vrindex", base + ".payload.jsonl", base + ".meta.json"
+
+    def save(self, directory: str | None = None) -> str:
+        """Persist the collection: the device image (Engine.save), one JSON line per row for the
+        host table (point id + payload, ``null`` for deleted rows) and the folder dictionaries.
+        Returns the directory. Each file is written to ``*.tmp`` and renamed."""
+        directory = directory or get_settings().index_dir
+        if not directory:
+            raise ValueError("no directory given and VOITTA_INDEX_DIR is not set")
+        os.makedirs(directory, exist_ok=True)
+        index_path, payload_path, meta_path = self._paths(directory)
+        col = self._col
+        with col.lock:
+            self.client.save(index_path)
+            with open(payload_path + ".tmp", "w", encoding="utf-8") as f:
+                for pid, payload in zip(col.ids, col.payload):
+                    f.write("null\n" if payload is None else json.dumps({"id": pid, "payload": payload}) + "\n")
+            os.replace(payload_path + ".tmp", payload_path)
+            meta = {"format": 1, "dimension": self.dimension, "rows": len(col.ids),
+                    "folder_ids": col.folder_ids, "index_folder_ids": col.index_folder_ids}
+            with open(meta_path + ".tmp", "w", encoding="utf-8") as f:
+                json.dump(meta, f)
+            os.replace(meta_path + ".tmp", meta_path)
+        return directory
+
+    def load(self, directory: str | None = None) -> int:
+        """Restore a collection written by save() into the (empty) engine; returns the row count."""
+        directory = directory or get_settings().index_dir
+        if not directory:
+            raise ValueError("no directory given and VOITTA_INDEX_DIR is not set")
+        col = self._col
+        if col.ids:
+            raise RuntimeError("collection is not empty")
+        return self._load_into(col, directory)
+
+    def _load_into(self, col: _Collection, directory: str) -> int:
+        index_path, payload_path, meta_path = self._paths(directory)
+        meta = json.load(open(meta_path, encoding="utf-8"))
+        if meta.get("format") != 1 or meta["dimension"] != self.dimension:
+            raise ValueError(f"{meta_path}: format/dimension mismatch ({meta.get('format')}, {meta.get('dimension')})")
+        with col.lock:
+            self._client.load(index_path)
+            for line in open(payload_path, encoding="utf-8"):
+                rec = json.loads(line)
+                row = len(col.ids)
+                if rec is None:
+                    col.ids.append(None)
+                    col.payload.append(None)
+                    continue
+                col.ids.append(rec["id"])
+                col.payload.append(rec["payload"])
+                col.row_of[rec["id"]] = row
+                col.rows_by_file.setdefault(rec["payload"]["file_path"], []).append(row)
+            col.folder_ids = {k: int(v) for k, v in meta["folder_ids"].items()}
+            col.index_folder_ids = {k: int(v) for k, v in meta["index_folder_ids"].items()}
+            n_rows, _ = self._client.count()
+            if n_rows != len(col.ids) or meta["rows"] != n_rows:
+                raise ValueError(f"{directory}: index holds {n_rows} rows, host table {len(col.ids)}")
+        logger.info("Loaded %d rows of collection '%s' from %s", len(col.ids), self.collection_name, directory)
+        return len(col.ids)
 
     @property
     def _col(self) -> _Collection:
