@@ -273,6 +273,17 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem,
  * save. The file is checksummed; a truncated or corrupt file is refused. Payload text, point ids
  * and the folder dictionaries belong to the host (voitta_rag_amd/vector_store.py saves them beside it). */
 int vr_save(vr_engine* e, const char* path);
+
+/* Reclaim tombstoned rows. The reference deletes points in place while it
+ * serves (watcher deletes, re-index = delete + insert, orphan purge: services/indexing.py:281-288,
+ * 696-721,886-901, watcher.py:149-171) and Qdrant's optimiser compacts segments in the background;
+ * here vr_delete_rows leaves tombstones and this call rebuilds every table without them.
+ * Surviving rows keep their relative order and are renumbered 0..n_live-1:
+ *   new_row_of_old  host int64[rows before the call] (may be NULL): new row, or -1 for a dropped row
+ *   n_rows_after    rows (= live rows) after the call
+ * Scores and rankings are unchanged (document frequencies and the sparse point count never
+ * included deleted rows). Runs under the engine's mutex: searches wait, none sees a partial state. */
+int vr_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after);
 int vr_load(vr_engine* e, const char* path);
 
 /* The fusion arithmetic alone (host, no GPU): what vector_store.py:659-697 does to two result

@@ -124,3 +124,53 @@ def test_empty_engine_round_trip(gpu, tmp_path):
     wr, ws = ocore.topk(sc, 5)
     gr, gs = e2.search_dense(x[:1], 5)[0]
     assert np.array_equal(gr, wr) and np.array_equal(gs, ws)
+
+
+@pytest.mark.parametrize("dim,n", [(64, 6000), (768, 5000), (48, 900)])
+def test_compact_drops_tombstones_and_keeps_every_answer(gpu, dim, n):
+    """vr_compact: after compaction every search returns the same documents with the
+    same f32 score bits; rows are renumbered in order; the engine keeps accepting upserts/deletes and
+    stays equal to an engine that was built from the surviving rows only."""
+    from voitta_rag_amd import Engine, SearchFilter
+
+    rng = np.random.default_rng(n)
+    e = Engine(dim)
+    x, (off, idx, val), folder, modified = _fill(e, rng, n, dim)
+    x2 = rng.standard_normal((200, dim)).astype(np.float32)
+    e.upsert(x2, folder_ids=np.full(200, 1, np.int32))            # rows without a sparse vector
+    dead = np.sort(rng.choice(n + 200, size=(n + 200) // 3, replace=False))
+    e.delete_rows(dead)
+    flt = SearchFilter(include_folders=[0, 1])
+    before = _queries(e, np.random.default_rng(5), dim, flt)
+    n_rows, n_live = e.count()
+    remap = e.compact()
+    assert remap.shape == (n_rows,) and (remap[dead] == -1).all()
+    keep = np.flatnonzero(remap >= 0)
+    assert np.array_equal(remap[keep], np.arange(keep.size)) and e.count() == (n_live, n_live)
+    after = _queries(e, np.random.default_rng(5), dim, flt)
+
+    def renumber(res):   # map the pre-compaction rows of a result through remap, keep scores
+        if isinstance(res, tuple) and len(res) and isinstance(res[0], np.ndarray) and res[0].dtype == np.int64:
+            return (remap[res[0]],) + tuple(res[1:])
+        if isinstance(res, (tuple, list)):
+            return type(res)(renumber(r) for r in res)
+        return res
+
+    _same(renumber(before), after)
+    # a second engine built from the survivors only must be indistinguishable, also after more traffic
+    e2 = Engine(dim)
+    allx = np.concatenate([x, x2])
+    sp_rows = [(idx[off[r]:off[r + 1]], val[off[r]:off[r + 1]]) for r in range(n)]
+    k0 = keep[keep < n]
+    e2.upsert(allx[k0], sparse=[sp_rows[r] for r in k0], folder_ids=folder[k0], modified=modified[k0])
+    k1 = keep[keep >= n]
+    e2.upsert(allx[k1], folder_ids=np.full(k1.size, 1, np.int32))
+    _same(after, _queries(e2, np.random.default_rng(5), dim, flt))
+    for eng in (e, e2):
+        _fill(eng, np.random.default_rng(42), 300, dim)
+        eng.delete_rows(np.arange(5, 900, 11))
+    _same(_queries(e, np.random.default_rng(6), dim, flt), _queries(e2, np.random.default_rng(6), dim, flt))
+    assert e.count() == e2.count()
+    assert e.compact().shape[0] == e2.count()[0] and e.count()[0] == e.count()[1]
+    e.close()
+    e2.close()

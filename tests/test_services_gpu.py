@@ -261,3 +261,38 @@ def test_collection_survives_a_restart(native, tmp_path, monkeypatch):
     assert np.array_equal(np.asarray(emb2.embed_query(texts[0]), np.float32), np.asarray(q, np.float32))
     more = vs2.store_chunks(list(zip(texts[:5], emb2.embed_texts(texts[:5]), metas[:5])), sparse_vectors=sp2.embed_texts(texts[:5]))
     assert len(more) == 5 and vs2.get_collection_info()["points_count"] == info["points_count"] + 5
+
+
+def test_compact_after_reindex_keeps_service_answers(native):
+    """Re-index = delete_by_file + store_chunks (indexing.py:281-288); compact() reclaims the rows and
+    nothing a caller can observe changes."""
+    native()
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import ChunkMetadata, VectorStoreService
+
+    rng = np.random.default_rng(21)
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), VectorStoreService()
+
+    def index(fp, texts):
+        metas = [ChunkMetadata(file_path=fp, folder_path="docs", index_folder="docs", file_name=os.path.basename(fp),
+                               chunk_index=i, total_chunks=len(texts), start_char=0, end_char=9,
+                               indexed_at="2026-01-01T00:00:00") for i in range(len(texts))]
+        return vs.store_chunks(list(zip(texts, emb.embed_texts(texts), metas)), sparse_vectors=sp.embed_texts(texts))
+
+    t = {fp: _texts(rng, 25) for fp in ("docs/a.md", "docs/b.md", "docs/c.md")}
+    for fp, texts in t.items():
+        index(fp, texts)
+    for _ in range(3):                                   # the same file re-indexed three times
+        assert vs.delete_by_file("docs/b.md") == 25
+        index("docs/b.md", t["docs/b.md"])
+    q, sq = emb.embed_query(t["docs/b.md"][3]), sp.embed_query(t["docs/b.md"][3])
+    want = [(c.id, c.score, c.text) for c in vs.search(q, limit=10, sparse_query=sq)]
+    info = vs.get_collection_info()
+    assert vs.compact(min_dead_fraction=0.9) == 0        # 75 dead of 150: below the threshold
+    assert vs.compact() == 75
+    assert vs.client.count() == (75, 75)
+    assert [(c.id, c.score, c.text) for c in vs.search(q, limit=10, sparse_query=sq)] == want
+    assert vs.get_collection_info() == info and vs.count_by_file("docs/b.md") == 25
+    assert vs.delete_by_file("docs/a.md") == 25 and vs.compact() == 25 and vs.compact() == 0
+    assert [c.metadata.chunk_index for c in vs.get_chunks_by_range("docs/c.md", 3, 5)] == [3, 4, 5]

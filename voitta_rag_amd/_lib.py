@@ -107,6 +107,7 @@ SIGNATURES = {
     "vr_profile_read": (C.c_int, [_vp, C.c_int, _dp, _i64p, _dp]),
     "vr_search_hybrid": (C.c_int, [_vp, _vp, C.c_int, _i32p, _fp, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                    C.POINTER(VrFilter), _i64p, _dp, _i32p, _i32p]),
+    "vr_compact": (C.c_int, [_vp, _i64p, _i64p]),
     "vr_save": (C.c_int, [_vp, C.c_char_p]),
     "vr_load": (C.c_int, [_vp, C.c_char_p]),
     "vr_fuse_minmax": (C.c_int, [_i64p, _fp, C.c_int32, _i64p, _fp, C.c_int32, C.c_int32, C.c_double, C.c_int32,

@@ -677,6 +677,12 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
                   out_count);
 }
 
+int vr_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after) {
+  VR_TRY(check_engine(e));
+  std::lock_guard<std::mutex> lock(e->mu);
+  return engine_compact(e, new_row_of_old, n_rows_after);
+}
+
 int vr_save(vr_engine* e, const char* path) {
   VR_TRY(check_engine(e));
   VR_CHECK(path && *path, "null path");

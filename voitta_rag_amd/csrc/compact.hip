@@ -1,0 +1,190 @@
+// vr_compact: rebuild the index without its tombstoned rows. The reference
+// deletes points in place (watcher deletes, re-index = delete + insert, orphan purge: reference
+// services/indexing.py:281-288,696-721,886-901, watcher.py:149-171) and Qdrant's optimiser reclaims
+// the space in the background; here deletes are tombstones and this call is the reclaim step.
+// Surviving rows keep their relative order, so ranking ties (lower row first) are unchanged; the
+// document-frequency table and the sparse point count already exclude deleted rows (vr_delete_rows
+// maintains them), so scores are bit-identical before and after.
+
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace vr {
+
+namespace {
+
+// one wave per surviving row: copy its D floats between the two tiled images
+__global__ __launch_bounds__(256) void gather_dense_kernel(const float* __restrict__ src, const int32_t* __restrict__ old_of_new,
+                                                           int64_t n_new, int dim, int kblocks, float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r_new = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (r_new >= n_new) return;
+  const int64_t r_old = old_of_new[r_new];
+  const int64_t to = r_old / kTileRows, tn = r_new / kTileRows;
+  const int ro = static_cast<int>(r_old % kTileRows), rn = static_cast<int>(r_new % kTileRows);
+  for (int k = lane; k < dim; k += 64) {
+    const int kb = k / kTileK, kk = k % kTileK;
+    const int64_t in_tile = (static_cast<int64_t>(kb) * 64 + (kk % 4) * 16) * 4 + kk / 4;
+    dst[tn * kblocks * 256 + in_tile + rn * 4] = src[to * kblocks * 256 + in_tile + ro * 4];  // 256 floats per 1-KiB block
+  }
+}
+
+template <class T>
+__global__ void gather_column_kernel(const T* __restrict__ src, const int32_t* __restrict__ old_of_new, int64_t n_new,
+                                     T* __restrict__ dst) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_new) dst[i] = src[old_of_new[i]];
+}
+
+// entries of a surviving row inside its old SELL slice
+__global__ void count_entries_kernel(const int32_t* __restrict__ old_of_new, int64_t n_new,
+                                     const int32_t* __restrict__ row_slice, const SliceDesc* __restrict__ slices,
+                                     const int32_t* __restrict__ sidx, int32_t* __restrict__ cnt) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int32_t r = old_of_new[i];
+  const int32_t s = row_slice[r];
+  int c = 0;
+  if (s >= 0) {
+    const SliceDesc d = slices[s];
+    const int lane = r - d.row_base;
+    while (c < d.width && sidx[d.off + static_cast<int64_t>(c >> 2) * 256 + lane * 4 + (c & 3)] >= 0) ++c;
+  }
+  cnt[i] = c;
+}
+
+__global__ void extract_entries_kernel(const int32_t* __restrict__ old_of_new, int64_t n_new,
+                                       const int32_t* __restrict__ row_slice, const SliceDesc* __restrict__ slices,
+                                       const int32_t* __restrict__ sidx, const float* __restrict__ sval,
+                                       const int64_t* __restrict__ begin, int32_t* __restrict__ idx,
+                                       float* __restrict__ val, uint8_t* __restrict__ has_sparse) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int32_t r = old_of_new[i];
+  const int32_t s = row_slice[r];
+  has_sparse[i] = s >= 0;
+  if (s < 0) return;
+  const SliceDesc d = slices[s];
+  const int lane = r - d.row_base;
+  const int n = static_cast<int>(begin[i + 1] - begin[i]);
+  for (int j = 0; j < n; ++j) {
+    const int64_t at = d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3);
+    idx[begin[i] + j] = sidx[at];
+    val[begin[i] + j] = sval[at];
+  }
+}
+
+// rows that never had a sparse vector keep row_slice = -1 (deleting them must not touch the point count)
+__global__ void restore_no_sparse_kernel(const uint8_t* __restrict__ has_sparse, int64_t n_new, int32_t* __restrict__ row_slice) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_new && !has_sparse[i]) row_slice[i] = -1;
+}
+
+template <class T>
+int gather_column(vr_engine* e, DevArray<T>& col, const int32_t* old_of_new, int64_t n_new) {
+  DevArray<T> fresh;
+  VR_TRY(fresh.grow(col.cap, 0, e->stream));
+  if (n_new > 0)
+    hipLaunchKernelGGL((gather_column_kernel<T>), dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, e->stream,
+                       col.p, old_of_new, n_new, fresh.p);
+  VR_HIP(hipStreamSynchronize(e->stream));
+  col.release();
+  col = fresh;
+  return 0;
+}
+
+}  // namespace
+
+int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after) {
+  VR_HIP(hipStreamSynchronize(e->stream));
+  const int64_t n_old = e->n_rows;
+  std::vector<uint8_t> live(static_cast<size_t>(n_old));
+  if (n_old) VR_HIP(hipMemcpy(live.data(), e->live.p, static_cast<size_t>(n_old), hipMemcpyDeviceToHost));
+  std::vector<int32_t> old_of_new;
+  old_of_new.reserve(static_cast<size_t>(e->n_live));
+  for (int64_t r = 0; r < n_old; ++r) {
+    const bool keep = live[static_cast<size_t>(r)] != 0;
+    if (new_row_of_old) new_row_of_old[r] = keep ? static_cast<int64_t>(old_of_new.size()) : -1;
+    if (keep) old_of_new.push_back(static_cast<int32_t>(r));
+  }
+  const int64_t n_new = static_cast<int64_t>(old_of_new.size());
+  VR_CHECK(n_new == e->n_live, "live-row count %lld does not match the bitmap (%lld)", static_cast<long long>(e->n_live),
+           static_cast<long long>(n_new));
+  if (n_rows_after) *n_rows_after = n_new;
+  if (n_new == n_old) return 0;  // nothing to reclaim
+  hipStream_t s = e->stream;
+  DevArray<int32_t> map;
+  VR_TRY(map.grow(std::max<int64_t>(n_new, 1), 0, s));
+  if (n_new) VR_HIP(hipMemcpyAsync(map.p, old_of_new.data(), sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyHostToDevice, s));
+
+  // ---- sparse rows out of the old slices, into a temporary CSR (before row_slice is re-packed)
+  DevArray<int32_t> cnt, tmp_idx;
+  DevArray<float> tmp_val;
+  DevArray<int64_t> begin;
+  DevArray<uint8_t> has_sparse;
+  std::vector<int32_t> cnt_host(static_cast<size_t>(n_new));
+  std::vector<int64_t> begin_host(static_cast<size_t>(n_new) + 1, 0);
+  const bool any_sparse = !e->slices_host.empty() && n_new > 0;
+  if (any_sparse) {
+    const unsigned blocks = static_cast<unsigned>((n_new + 255) / 256);
+    VR_TRY(cnt.grow(n_new, 0, s));
+    hipLaunchKernelGGL(count_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
+                       e->sp_idx.p, cnt.p);
+    VR_HIP(hipMemcpyAsync(cnt_host.data(), cnt.p, sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyDeviceToHost, s));
+    VR_HIP(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n_new; ++i) begin_host[static_cast<size_t>(i) + 1] = begin_host[static_cast<size_t>(i)] + cnt_host[static_cast<size_t>(i)];
+    const int64_t nnz = begin_host.back();
+    VR_TRY(begin.grow(n_new + 1, 0, s));
+    VR_TRY(tmp_idx.grow(std::max<int64_t>(nnz, 1), 0, s));
+    VR_TRY(tmp_val.grow(std::max<int64_t>(nnz, 1), 0, s));
+    VR_TRY(has_sparse.grow(n_new, 0, s));
+    VR_HIP(hipMemcpyAsync(begin.p, begin_host.data(), sizeof(int64_t) * (static_cast<size_t>(n_new) + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(extract_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
+                       e->sp_idx.p, e->sp_val.p, begin.p, tmp_idx.p, tmp_val.p, has_sparse.p);
+    VR_HIP(hipStreamSynchronize(s));
+  }
+
+  // ---- dense image and payload columns
+  {
+    DevArray<float> fresh;
+    VR_TRY(fresh.grow(e->corpus.cap, 0, s));
+    if (n_new)
+      hipLaunchKernelGGL(gather_dense_kernel, dim3(static_cast<unsigned>((n_new + 3) / 4)), dim3(256), 0, s, e->corpus.p, map.p,
+                         n_new, e->dim, e->kblocks, fresh.p);
+    VR_HIP(hipStreamSynchronize(s));
+    e->corpus.release();
+    e->corpus = fresh;
+  }
+  VR_TRY(gather_column(e, e->folder, map.p, n_new));
+  VR_TRY(gather_column(e, e->index_folder, map.p, n_new));
+  VR_TRY(gather_column(e, e->created, map.p, n_new));
+  VR_TRY(gather_column(e, e->modified, map.p, n_new));
+  VR_HIP(hipMemsetAsync(e->live.p, 1, static_cast<size_t>(n_new), s));
+  VR_HIP(hipMemsetAsync(e->live.p + n_new, 0, static_cast<size_t>(e->cap_rows - n_new), s));
+  VR_HIP(hipMemsetAsync(e->row_slice.p, 0xFF, sizeof(int32_t) * static_cast<size_t>(e->cap_rows), s));  // -1
+
+  // ---- sparse index re-packed in the new row order; df table and point count stay as they are
+  e->slices_host.clear();
+  e->n_slices_dev = 0;
+  e->sp_used = 0;
+  e->n_rows = n_new;
+  if (any_sparse) {
+    VR_TRY(sparse_append(e, n_new, 0, cnt_host.data(), begin.p, nullptr, tmp_idx.p, tmp_val.p, /*account=*/false));
+    hipLaunchKernelGGL(restore_no_sparse_kernel, dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, s,
+                       has_sparse.p, n_new, e->row_slice.p);
+  }
+  VR_TRY(prefilter_store_rows(e, n_new, 0));
+  VR_HIP(hipStreamSynchronize(s));
+  VR_HIP(hipGetLastError());
+  map.release();
+  cnt.release();
+  tmp_idx.release();
+  tmp_val.release();
+  begin.release();
+  has_sparse.release();
+  return 0;
+}
+
+}  // namespace vr

@@ -243,7 +243,11 @@ int sparse_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val
 // rows of the batch live at idx/val[begin[r] .. +count); count = cnt_dev[r] or begin[r+1]-begin[r]
 int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
                   const int64_t* begin_dev, const int32_t* cnt_dev, const int32_t* idx_dev,
-                  const float* val_dev);
+                  const float* val_dev, bool account = true);  // account: count df and points (not when re-packing)
+
+// ---- compact.hip: drop tombstoned rows (vr_compact)
+int engine_compact(vr_engine* e, int64_t* new_row_of_old_host, int64_t* n_rows_after);
+
 // ---- bm25.hip
 int bm25_tf(vr_engine* e, const int64_t* tok_off_dev, const int32_t* tok_ids_dev, int64_t n_docs,
             int64_t n_tokens, double k, double b, double avg_len, int32_t* out_cnt_dev,

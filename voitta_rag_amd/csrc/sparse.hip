@@ -162,14 +162,14 @@ __global__ void df_update_region_kernel(const int32_t* __restrict__ sidx, int64_
 
 int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
                   const int64_t* begin_dev, const int32_t* cnt_dev, const int32_t* idx_dev,
-                  const float* val_dev) {
+                  const float* val_dev, bool account) {
   if (n <= 0) return 0;
   int64_t nnz = 0;
   for (int64_t r = 0; r < n; ++r) {
     VR_CHECK(cnt_host[r] >= 0, "negative sparse row length");
     nnz += cnt_host[r];
   }
-  VR_TRY(df_ensure(e, nnz));
+  if (account) VR_TRY(df_ensure(e, nnz));
 
   const int64_t slice0 = static_cast<int64_t>(e->slices_host.size());
   int64_t used = e->sp_used;
@@ -197,14 +197,14 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
                      e->slices.p, slice0, first_row, begin_dev, cnt_dev, idx_dev, val_dev, e->sp_idx.p,
                      e->sp_val.p, e->row_slice.p);
   const int64_t region = used - e->sp_used;
-  if (region > 0)
+  if (region > 0 && account)
     hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((region + 255) / 256)),
                        dim3(256), 0, e->stream, e->sp_idx.p, e->sp_used, used, e->df_keys.p,
                        e->df_cnt.p, e->df_cap, e->df_distinct);
   VR_HIP(hipGetLastError());
   e->sp_used = used;
   e->n_slices_dev = static_cast<int64_t>(e->slices_host.size());
-  e->n_sparse_points += n;
+  if (account) e->n_sparse_points += n;
   return 0;
 }
 

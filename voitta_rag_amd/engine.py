@@ -261,6 +261,15 @@ class Engine:
             out[name] = int(v.value)
         return out
 
+    def compact(self) -> np.ndarray:
+        """Drop tombstoned rows; surviving rows are renumbered in order. Returns new_row_of_old
+        (int64, -1 for dropped rows) so the caller can renumber whatever it keys by row."""
+        n_rows, _ = self.count()
+        remap = np.empty(n_rows, np.int64)
+        after = C.c_int64()
+        check(self._lib.vr_compact(self._h, _ptr(remap, C.c_int64), C.byref(after)))
+        return remap
+
     def save(self, path: str) -> None:
         """Write the device-resident index (dense, sparse, payload columns, tombstones, document
         frequencies) to one checksummed file; the write is atomic (tmp + rename)."""

@@ -129,6 +129,31 @@ class VectorStoreService:
             self._load_into(col, index_dir)
         self._has_sparse = True  # every collection is created with the "bm25" sparse vector (:95-99,114)
 
+    # ---- compaction -----------------------------------------------------------
+    def compact(self, min_dead_fraction: float = 0.0) -> int:
+        """Reclaim the rows of deleted points (delete_by_file on re-index, watcher deletes, orphan
+        purge: indexing.py:281-288,696-721,886-901) — the role of Qdrant's background optimiser.
+        Returns the number of rows dropped; does nothing below ``min_dead_fraction`` tombstones."""
+        col = self._col
+        with col.lock:
+            total = len(col.ids)
+            dead = sum(1 for p in col.payload if p is None)
+            if dead == 0 or dead < min_dead_fraction * total:
+                return 0
+            remap = self.client.compact()
+            ids, payload = [], []
+            for pid, p in zip(col.ids, col.payload):
+                if p is not None:
+                    ids.append(pid)
+                    payload.append(p)
+            col.ids, col.payload = ids, payload
+            col.row_of = {pid: r for r, pid in enumerate(ids)}
+            col.rows_by_file = {}
+            for r, p in enumerate(payload):
+                col.rows_by_file.setdefault(p["file_path"], []).append(r)
+            assert int((remap >= 0).sum()) == len(ids)
+            return dead
+
     # ---- persistence (SURVEY.md §8 row f2) ---------------------------------------------------------
     def _paths(self, directory: str) -> tuple[str, str, str]:
         base = os.path.join(directory, self.collection_name)
