@@ -150,6 +150,25 @@ int vr_encoder_load(vr_engine* e, const vr_bert_desc* desc, const void* const* t
 int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t n_seq, int mem,
               float* out, int out_mem);
 
+/* Host-only WordPiece tokenizer (no engine, no GPU): the tokenise step of SentenceTransformer.encode
+ * (embedding.py:40,68-73 -> [EXT] HF tokenizers: BertNormalizer, BertPreTokenizer, WordPiece,
+ * "[CLS] $A [SEP]", right truncation — SURVEY.md §8 a4 step 2), producing the ids / offsets vr_encode
+ * and vr_index_batch take.
+ *   vocab_tokens   n_vocab NUL-terminated UTF-8 strings, id = index (vocab.txt line order); must
+ *                  contain [UNK], [CLS], [SEP]
+ *   lowercase      do_lower_case; strip_accents: 0 / 1, or -1 = follow lowercase (the HF default)
+ *   texts[i]       text_lens[i] bytes of UTF-8 (malformed bytes are dropped like U+FFFD)
+ *   max_len        longest sequence including [CLS] and [SEP] (max_seq_length)
+ *   out_offsets    n_texts + 1; out_ids: at most `capacity` ids written; *needed: total count
+ * Returns -2 (offsets and *needed valid) when the buffer is too small. Thread-safe: the tokenizer
+ * object is read-only after creation. */
+typedef struct vr_wordpiece vr_wordpiece;
+int vr_wordpiece_create(const char* const* vocab_tokens, int32_t n_vocab, int32_t lowercase, int32_t strip_accents,
+                        int32_t handle_chinese_chars, int32_t clean_text, vr_wordpiece** out);
+void vr_wordpiece_destroy(vr_wordpiece* t);
+int vr_wordpiece_encode(const vr_wordpiece* t, const char* const* texts, const int64_t* text_lens, int64_t n_texts,
+                        int32_t max_len, int64_t* out_offsets, int32_t* out_ids, int64_t capacity, int64_t* needed);
+
 /* ---- BM25 document side: replaces SparseTextEmbedding("Qdrant/bm25").embed's token-count / TF
  * weighting (sparse_embedding.py:25,49; scripts/build_sparse_vectors.py:124,170) -- */
 /* tok_off: n_docs+1 offsets, tok_ids: abs(murmur3) of each stemmed token in text order (`mem`).

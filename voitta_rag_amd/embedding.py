@@ -18,6 +18,7 @@ import numpy as np
 from . import encoder as _enc
 from .config import get_settings
 from .store_registry import get_engine
+from .wordpiece import WordPieceTokenizer
 
 logger = logging.getLogger(__name__)
 
@@ -30,8 +31,11 @@ class NativeSentenceEncoder:
         self.desc = desc
         self.tokenizer = tokenizer
         self.max_seq_length = min(max_seq_length, desc.max_pos)
-        self.tokenizer.no_padding()
-        self.tokenizer.enable_truncation(max_length=self.max_seq_length)
+        if isinstance(tokenizer, WordPieceTokenizer):
+            tokenizer.max_length = self.max_seq_length
+        else:
+            self.tokenizer.no_padding()
+            self.tokenizer.enable_truncation(max_length=self.max_seq_length)
         _enc.load_encoder(engine, desc, state)
 
     # ---- loading ---------------------------------------------------------------------------------
@@ -88,9 +92,25 @@ class NativeSentenceEncoder:
 
     @staticmethod
     def _load_tokenizer(path: str, cfg: dict):
+        """The native WordPiece (csrc/wordpiece.cpp) for plain BERT tokenizers; anything else that a
+        tokenizer.json may describe goes through the HF `tokenizers` library."""
+        tj = os.path.join(path, "tokenizer.json")
+        if os.path.exists(os.path.join(path, "vocab.txt")) or os.path.exists(tj):
+            try:
+                if os.path.exists(tj):
+                    spec = json.load(open(tj, encoding="utf-8"))
+                    plain = (spec["model"]["type"] == "WordPiece"
+                             and (spec.get("normalizer") or {}).get("type") == "BertNormalizer"
+                             and (spec.get("pre_tokenizer") or {}).get("type") == "BertPreTokenizer"
+                             and spec["model"].get("continuing_subword_prefix", "##") == "##"
+                             and spec["model"].get("max_input_chars_per_word", 100) == 100)
+                    if not plain:
+                        raise ValueError("not a plain BERT WordPiece pipeline")
+                return WordPieceTokenizer.from_pretrained(path)
+            except (ValueError, KeyError) as e:
+                logger.info("native WordPiece not applicable (%s); using the tokenizers library", e)
         from tokenizers import Tokenizer
 
-        tj = os.path.join(path, "tokenizer.json")
         if os.path.exists(tj):
             return Tokenizer.from_file(tj)
         vocab = os.path.join(path, "vocab.txt")
@@ -104,6 +124,9 @@ class NativeSentenceEncoder:
 
     # ---- SentenceTransformer.encode -------------------------------------------------------------
     def tokenize(self, texts: list[str]):
+        if isinstance(self.tokenizer, WordPieceTokenizer):
+            ids, off = self.tokenizer.encode_batch(list(texts))
+            return ids, off.astype(np.int32)
         encs = self.tokenizer.encode_batch(list(texts))
         lens = [len(e.ids) for e in encs]
         off = np.zeros(len(texts) + 1, np.int32)
