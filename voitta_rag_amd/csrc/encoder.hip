@@ -208,10 +208,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
                                                    const int32_t* __restrict__ cu, int seq0,
                                                    int tok_base, int H, int pooling, int normalize,
-                                                   float* __restrict__ out) {
+                                                   int compact, float* __restrict__ out) {
   __shared__ float red[4];
   const int seq = seq0 + blockIdx.x;
-  const int t0 = cu[seq] - tok_base;
+  // compact: x holds one row per sequence (its [CLS] row), see the last layer of forward_chunk
+  const int t0 = compact ? static_cast<int>(blockIdx.x) : cu[seq] - tok_base;
   const int len = cu[seq + 1] - cu[seq];
   float vals[4];
   float ss = 0.0f;
@@ -241,6 +242,19 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
     int c = threadIdx.x + 256 * j;
     if (c < H) out[static_cast<int64_t>(seq) * H + c] = vals[j] / den;
   }
+}
+
+// dst[i] = src[first token of sequence seq0 + i]; rows of `row_f4` float4s (an f32 row of H floats and
+// an interleaved (hi, lo) f16 row of 2H halfs have the same 4H bytes). One wave per row.
+__global__ __launch_bounds__(256) void gather_first_rows_kernel(const float4* __restrict__ src,
+                                                                const int32_t* __restrict__ cu, int seq0,
+                                                                int tok_base, int n, int T, int row_f4,
+                                                                float4* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int t = min(cu[seq0 + i] - tok_base, T - 1);  // an empty sequence reads a neighbour's row; pooling ignores it
+  for (int c = lane; c < row_f4; c += 64) dst[static_cast<int64_t>(i) * row_f4 + c] = src[static_cast<int64_t>(t) * row_f4 + c];
 }
 
 // ---- GEMM: C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU | + R) ---------------------------------------
@@ -1203,21 +1217,72 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
                      enc->x, xh, xl);
   const int qblocks = (max_len + 63) / 64;
   const float scale = 1.0f / sqrtf(static_cast<float>(dh));
-  for (const LayerWeights& w : enc->layers) {
+  // CLS pooling reads one row per sequence, so everything after the LAST layer's attention is needed
+  // for those rows only: their context rows (and residual rows) are gathered into compact [n_seq, *]
+  // matrices carved out of the qkv buffer (free once attention has run), and the output projection,
+  // both LayerNorms and the FFN run on n_seq rows instead of T. Every row's arithmetic is unchanged
+  // (a GEMM row does not depend on its neighbours), so the embeddings are bit-identical; for
+  // bge-base this removes 10/12 of the last layer's GEMM work. The Q projection of the other
+  // tokens is still computed (it is one GEMM with K and V).
+  const int n_seq = seq1 - seq0;
+  const bool cls_tail = d.pooling == VR_POOL_CLS && !enc->layers.empty() &&
+                        static_cast<int64_t>(n_seq) * (4 * H + I) <= static_cast<int64_t>(T) * 3 * H;
+  float* xc = enc->qkv;                                       // [n_seq, H] hidden state of the [CLS] rows
+  float* tmpc = xc + static_cast<int64_t>(n_seq) * H;         // [n_seq, H]
+  float* xsc = tmpc + static_cast<int64_t>(n_seq) * H;        // [n_seq, 2H] halfs (split) = n_seq*H floats
+  float* ctxc = xsc + static_cast<int64_t>(n_seq) * H;        // [n_seq, H] f32 or [n_seq, 2H] halfs
+  float* ffnc = ctxc + static_cast<int64_t>(n_seq) * H;       // [n_seq, I] f32 or [n_seq, 2I] halfs
+  for (size_t li = 0; li < enc->layers.size(); ++li) {
+    const LayerWeights& w = enc->layers[li];
+    const bool tail = cls_tail && li + 1 == enc->layers.size();
     if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
                                enc->qkv, nullptr, nullptr, T, 3 * H, H));
     else
       VR_TRY(launch_gemm(e, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
-    dim3 agrid(static_cast<unsigned>((seq1 - seq0) * qblocks), static_cast<unsigned>(nh));
-    prof_begin(e, VR_PROF_ATTENTION, attn_flop);
+    const int qb = tail ? 1 : qblocks;  // tail: only the query block that holds token 0 of every sequence
+    dim3 agrid(static_cast<unsigned>(n_seq * qb), static_cast<unsigned>(nh));
+    prof_begin(e, VR_PROF_ATTENTION, tail ? attn_flop / qblocks : attn_flop);
     if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
-                         qblocks, scale, enc->ctx, ch, cl);
+                         qb, scale, enc->ctx, ch, cl);
     else
       hipLaunchKernelGGL((attention_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
-                         qblocks, scale, enc->ctx, ch, cl);
+                         qb, scale, enc->ctx, ch, cl);
     prof_end(e);
+    if (tail) {
+      const unsigned gblocks = static_cast<unsigned>((n_seq + 3) / 4);
+      const unsigned cblocks = gblocks;
+      hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->ctx),
+                         cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(ctxc));
+      hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->x),
+                         cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(xc));
+      half_t* xch = reinterpret_cast<half_t*>(xsc);
+      half_t* cch = reinterpret_cast<half_t*>(ctxc);
+      half_t* fch = reinterpret_cast<half_t*>(ffnc);
+      if (split)
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, cch, cch + 8, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, xc, tmpc,
+                                 nullptr, nullptr, n_seq, H, H));
+      else
+        VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ctxc, w.wo, w.bo, xc, tmpc, n_seq, H, H));
+      hipLaunchKernelGGL(layernorm_kernel, dim3(cblocks), dim3(256), 0, s, tmpc, n_seq, H, w.ln1g, w.ln1b, d.eps, xc,
+                         split ? xch : nullptr, split ? xch + 8 : nullptr);
+      if (split) {
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xch, xch + 8, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr, nullptr,
+                                 fch, fch + 8, n_seq, I, H));
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, fch, fch + 8, w.s_2.hi, w.s_2.lo, w.s_2.unscale, w.b2, xc, tmpc,
+                                 nullptr, nullptr, n_seq, H, I));
+      } else {
+        VR_TRY(launch_gemm(e, EPI_BIAS_GELU, xc, w.w1, w.b1, nullptr, ffnc, n_seq, I, H));
+        VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ffnc, w.w2, w.b2, xc, tmpc, n_seq, H, I));
+      }
+      hipLaunchKernelGGL(layernorm_kernel, dim3(cblocks), dim3(256), 0, s, tmpc, n_seq, H, w.ln2g, w.ln2b, d.eps, xc,
+                         static_cast<half_t*>(nullptr), static_cast<half_t*>(nullptr));
+      hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(256), 0, s, xc, cu_dev, seq0, tok_base, H,
+                         d.pooling, d.normalize, 1, out_dev);
+      VR_HIP(hipGetLastError());
+      return 0;
+    }
     if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, ch, cl, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, enc->x,
                                enc->tmp, nullptr, nullptr, T, H, H));
@@ -1238,7 +1303,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
                        d.eps, enc->x, xh, xl);
   }
   hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(seq1 - seq0)), dim3(256), 0, s, enc->x, cu_dev,
-                     seq0, tok_base, H, d.pooling, d.normalize, out_dev);
+                     seq0, tok_base, H, d.pooling, d.normalize, 0, out_dev);
   VR_HIP(hipGetLastError());
   return 0;
 }
