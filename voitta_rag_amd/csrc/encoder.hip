@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
     const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
     float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
-    float unscale, int ablate) {
+    float unscale) {
   __shared__ half_t lds[4 * HBM_ * HLDT];  // [Ah, Al, Wh, Wl][128][HLDT] = 72 KiB
   const int tiles_n = N / HBN_;
   const int nwg = gridDim.x;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
   const half_t* pa = lds + (wm * 64 + frow) * HLDT + fk;
   const half_t* pw = lds + 2 * HBM_ * HLDT + (wn * 64 + frow) * HLDT + fk;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && !(ablate & 2)) VR_HLOAD((kt + 1) * HBK_);
+    if (kt + 1 < nk) VR_HLOAD((kt + 1) * HBK_);
 #pragma unroll
     for (int kk = 0; kk < HBK_; kk += 16) {
       f16x8 ah[2], al[2], wh[2], wl[2];
@@ -531,7 +531,6 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (ablate & 4) continue;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
@@ -570,7 +569,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(
     const int lr = it * 4 + (lane >> 4);
     const int grow = bm + wm * 64 + lr;
     float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
-    if (grow >= M || ((ablate & 1) && v.x == v.x)) continue;
+    if (grow >= M) continue;
     v.x = v.x * unscale + b4.x;
     v.y = v.y * unscale + b4.y;
     v.z = v.z * unscale + b4.z;
@@ -865,7 +864,6 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   VR_CHECK(N % HBN_ == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, HBN_, HBK_);
   if (M <= 0) return 0;
   hipStream_t s = e->stream;
-  static const int ablate = getenv("VR_GEMM_ABLATE") ? atoi(getenv("VR_GEMM_ABLATE")) : 0;  // timing experiments only
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
   if (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128) {
@@ -912,15 +910,15 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   switch (epi) {
     case EPI_BIAS:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R, C, Ch,
-                         Cl, M, N, K, unscale, ablate);
+                         Cl, M, N, K, unscale);
       break;
     case EPI_BIAS_GELU:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias, R,
-                         C, Ch, Cl, M, N, K, unscale, ablate);
+                         C, Ch, Cl, M, N, K, unscale);
       break;
     default:
       hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_RESIDUAL>), dim3(grid), dim3(256), 0, s, Ah, Al, Wh, Wl, bias,
-                         R, C, Ch, Cl, M, N, K, unscale, ablate);
+                         R, C, Ch, Cl, M, N, K, unscale);
       break;
   }
   prof_end(e);
