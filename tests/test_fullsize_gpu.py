@@ -1,0 +1,123 @@
+"""BASELINE configs[2] size (1M x 768) — where the CPU oracle is too slow to be the checker, parity
+is held through size-independent properties (the contract's list: sortedness, idempotence, merge of
+parts = whole, two independent code paths agreeing bit for bit) plus a spot check of the winners
+against the oracle's own arithmetic on the rows that matter."""
+import numpy as np
+import pytest
+
+from oracle import core as ocore
+
+pytestmark = pytest.mark.gpu
+
+N, D = 1_000_000, 768
+
+
+@pytest.fixture(scope="module")
+def corpus(gpu):
+    import torch
+
+    from voitta_rag_amd import Engine
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2026)
+    two = Engine(D, initial_rows=N)                      # f16 shadow + two-stage search
+    one = Engine(D, initial_rows=N, prefilter=False)     # one-stage f32 scan only
+    halves = [Engine(D, initial_rows=N // 2, prefilter=False), Engine(D, initial_rows=N // 2)]
+    nnz = 24
+    keep = []
+    for a in range(0, N, 125_000):
+        x = torch.randn((125_000, D), device=dev, generator=g)
+        x[:1000] = x[0] + 0.05 * torch.randn((1000, D), device=dev, generator=g)   # a cluster per block
+        ids = (torch.rand((125_000, nnz), device=dev, generator=g) ** 2 * 50_000).to(torch.int32)
+        ids, _ = torch.sort(ids, dim=1)
+        ids = ids * 32 + torch.arange(nnz, device=dev, dtype=torch.int32)[None, :]   # distinct, ascending
+        off = (torch.arange(125_001, device=dev, dtype=torch.int64) * nnz).contiguous()
+        val = torch.rand((125_000 * nnz,), device=dev, generator=g) + 0.5
+        sp = (off, ids.reshape(-1).contiguous(), val.contiguous())
+        for e in (two, one, halves[0] if a < N // 2 else halves[1]):
+            e.upsert(x.contiguous(), sparse=sp)
+        keep.append(x[:2000].cpu().numpy())              # enough to spot-check winners from the clusters
+    q = torch.randn((24, D), device=dev, generator=g)
+    q[:8] = torch.cat([torch.from_numpy(k[:1]) for k in keep]).to(dev) + 0.01 * torch.randn((8, D), device=dev, generator=g)
+    yield two, one, halves, q.cpu().numpy(), keep
+    for e in (two, one, *halves):
+        e.close()
+
+
+def test_two_code_paths_agree_bit_for_bit_and_results_are_sorted(corpus):
+    two, one, halves, q, keep = corpus
+    for i in range(q.shape[0]):
+        for k in (10, 30, 64):
+            r2, s2 = two.search_dense(q[i:i + 1], k)[0]
+            r1, s1 = one.search_dense(q[i:i + 1], k)[0]
+            assert np.array_equal(r2, r1) and np.array_equal(s2.view(np.uint32), s1.view(np.uint32)), (i, k)
+            assert len(r2) == k and len(set(r2.tolist())) == k
+            assert np.all(s2[:-1] >= s2[1:])                                             # sorted
+            ties = s2[:-1] == s2[1:]
+            assert np.all(r2[:-1][ties] < r2[1:][ties])                                  # ties: lower row first
+            ra, sa = two.search_dense(q[i:i + 1], k)[0]                                  # idempotent
+            assert np.array_equal(ra, r2) and np.array_equal(sa, s2)
+    st = two.stats()
+    assert st["two_stage"] >= q.shape[0] * 6 and st["fallback"] == 0
+    assert one.stats()["two_stage"] == 0
+    # a 16-query block through the batched one-stage scan equals the single-query answers
+    block = two.search_dense(q[:16], 10)
+    for i in range(16):
+        r, s = two.search_dense(q[i:i + 1], 10)[0]
+        assert np.array_equal(block[i][0], r) and np.array_equal(block[i][1], s)
+
+
+def test_merge_of_halves_equals_whole(corpus):
+    """Sharding invariance at full size: top-k of the union = merge of the per-shard top-k lists
+    (what sharded.py does over RCCL), dense and sparse, with global document frequencies."""
+    two, one, halves, q, keep = corpus
+    for i in range(0, q.shape[0], 3):
+        want_r, want_s = two.search_dense(q[i:i + 1], 30)[0]
+        parts = [h.search_dense(q[i:i + 1], 30)[0] for h in halves]
+        rows = np.concatenate([parts[0][0], parts[1][0] + N // 2])
+        scores = np.concatenate([parts[0][1], parts[1][1]])
+        order = np.lexsort((rows, -scores.astype(np.float64)))[:30]
+        assert np.array_equal(rows[order], want_r) and np.array_equal(scores[order], want_s)
+    qi = np.asarray([3 * 32 + 0, 100 * 32 + 1, 2000 * 32 + 5, 40_000 * 32 + 20], np.int32)
+    df = [sum(int(h.sparse_stats(qi)[0][j]) for h in halves) for j in range(len(qi))]
+    whole_df, n_pts = two.sparse_stats(qi)
+    assert [int(v) for v in whole_df] == df and n_pts == N
+    w = np.asarray([two.idf(N, d) for d in df], np.float32)                              # global statistics
+    want_r, want_s = two.search_sparse(qi, np.ones(4, np.float32), 30)
+    parts = [h.search_sparse(qi, w, 30, weights_given=True) for h in halves]
+    rows = np.concatenate([parts[0][0], parts[1][0] + N // 2])
+    scores = np.concatenate([parts[0][1], parts[1][1]])
+    order = np.lexsort((rows, -scores.astype(np.float64)))[:30]
+    assert np.array_equal(rows[order], want_r) and np.array_equal(scores[order], want_s)
+
+
+def test_winners_match_the_oracle_arithmetic(corpus):
+    """The first 8 queries sit next to the cluster heads, so their winners are among the rows kept
+    on the host: the engine's f32 scores for those rows must equal the oracle's fma chain bit for bit,
+    and every kept row must rank exactly where its oracle score puts it."""
+    two, one, halves, q, keep = corpus
+    for b in range(8):
+        rows, scores = two.search_dense(q[b:b + 1], 64)[0]
+        base = b * 125_000
+        local = (rows >= base) & (rows < base + 2000)
+        assert local.sum() >= 32                                                         # the cluster dominates
+        xh = ocore.cosine_preprocess(keep[b])
+        sc = ocore.dense_scores(ocore.cosine_preprocess(q[b:b + 1]), xh)[0]
+        got = scores[local]
+        want = sc[rows[local] - base]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # no kept row outside the result may beat the last returned score
+        outside = np.setdiff1d(np.arange(2000), rows[local] - base)
+        assert np.all(sc[outside] <= scores[-1])
+
+
+def test_deletes_at_full_size(corpus):
+    two, one, halves, q, keep = corpus
+    r, s = two.search_dense(q[:1], 10)[0]
+    for e in (two, one):
+        e.delete_rows(r[:5])
+    r2, s2 = two.search_dense(q[:1], 10)[0]
+    r1, s1 = one.search_dense(q[:1], 10)[0]
+    assert np.array_equal(r2, r1) and np.array_equal(s2, s1)
+    assert not set(r[:5].tolist()) & set(r2.tolist()) and np.array_equal(r2[:5], r[5:])
+    assert two.count() == (N, N - 5)
