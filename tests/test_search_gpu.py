@@ -199,7 +199,7 @@ def test_rows_without_sparse_vectors_and_empty_engine(gpu):
 @pytest.mark.parametrize("dim,n", [(768, 20000), (384, 9000), (1024, 5000), (64, 6000), (96, 5000)])
 def test_two_stage_dense_search_is_bit_identical(gpu, dim, n):
     """Stores with dim % 32 == 0 and >= 4096 rows answer single-query dense searches through the
-    f16 prefilter + exact re-score (dense8.hip). Rows, scores and order must equal the oracle's —
+    f16 prefilter + exact re-score (prefilter.hip). Rows, scores and order must equal the oracle's —
     and therefore the one-stage scan's — bit for bit, with filters and tombstones in play."""
     from voitta_rag_amd import SearchFilter
 

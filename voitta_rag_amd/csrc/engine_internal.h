@@ -121,7 +121,7 @@ struct vr_engine {
 
   // dense corpus, MFMA-tiled: [row/16][k/16][lane = (k%4)*16 + row%16][c = (k%16)/4]
   vr::DevArray<float> corpus;
-  // f16 shadow of the corpus for the two-stage exact search (dense8.hip), present when dim % 32 == 0
+  // f16 shadow of the corpus for the two-stage exact search (prefilter.hip), present when dim % 32 == 0
   // and not disabled: [row/16][k/32][lane = (k%32)/8*16 + row%16][8 halfs], plus the exact
   // rounding residual |x - f16(x)|_2 of every row.
   bool prefilter = false;
@@ -220,7 +220,7 @@ int dense_make_query_image(vr_engine* e, const float* q_dev, int nq);
 int dense_scores(vr_engine* e, int nq, const uint8_t* mask_dev);
 int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out_dev);
 
-// ---- dense8.hip: f16 prefilter + exact re-score (two-stage exact search)
+// ---- prefilter.hip: f16 prefilter + exact re-score (two-stage exact search)
 int prefilter_store_rows(vr_engine* e, int64_t n, int64_t first_row);
 bool prefilter_usable(vr_engine* e, int nq, int k);
 int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev, int32_t* out_count_dev);
