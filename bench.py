@@ -19,9 +19,10 @@ Weak scaling: every rank owns its own 1M-row shard and indexes its own batches (
 the indexing path); queries merge per-shard top-k lists with one RCCL all_gather per list.
 
 Data: synthetic (seeded), weights random-init N(0, 0.02) of the named architecture — there is no
-network for checkpoints. dtype: --precision f16x3 (default; every operand carried as hi + lo f16 =
-22 significant bits, three f16-MFMA passes, f32 accumulate; |1 - cos| ~5e-8 against the f64
-oracle) or f32 (every product on the f32-input MFMA).
+network for checkpoints. dtype: --precision f16 (default: f16 operands on the f16 MFMA, f32
+accumulate, everything outside the matrix products in f32; |1 - cos| = 2e-6 against the f64 oracle
+at the full 12 layers, north_star allows 1e-4), f16x3 (every operand carried as hi + lo f16 = 22 significant bits, three
+f16-MFMA passes; |1 - cos| ~5e-8) or f32 (every product on the f32-input MFMA).
 
 Prints ONE JSON line on rank 0.
 """
@@ -56,9 +57,10 @@ def parse():
     p.add_argument("--queries", type=int, default=1000)
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
-                   help="encoder matrix products: exact f32 MFMA, or (hi,lo) f16 split x3 passes (f32-class "
-                        "accuracy, same parity bar: tests/test_encoder_gpu.py)")
+    p.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16"],
+                   help="encoder matrix products: f16 operands / f32 accumulate (default; |1-cos| = 2e-6 vs the f64 "
+                        "oracle at full depth, north_star allows 1e-4), (hi,lo) f16 split x3 passes (f32-class), or "
+                        "the f32-input MFMA; tests/test_encoder_gpu.py holds all three")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     p.add_argument("--share-gpu", action="store_true",
                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
@@ -343,6 +345,9 @@ def main():
 
     if rank == 0:
         gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # ceiling for ALGORITHMIC FLOP/s: the f32 MFMA peak, the dense f16 peak, or a third of it (three passes)
+        gemm_peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS,
+                     "f16x3": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1)}[args.precision]
         scan_gbps = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
             "metric": "chunks indexed/sec + p50 top-10 query latency @1M-chunk corpus, 1/8 MI355X",
@@ -355,9 +360,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else
-                     "f16x3 (operands as hi+lo f16 = 22 significant bits, three f16-MFMA passes, f32 accumulate; "
-                     "measured |1-cos| < 1e-6 vs the f64 oracle, the same bar as the f32 path)",
+            "dtype": {"f32": "f32",
+                      "f16x3": "f16x3 (operands as hi+lo f16 = 22 significant bits, three f16-MFMA passes, f32 "
+                               "accumulate; measured |1-cos| ~5e-8 vs the f64 oracle)",
+                      "f16": "f16 (f16 MFMA operands, f32 accumulate; attention, LayerNorm, GELU, pooling in f32; "
+                             "measured |1-cos| = 2.0e-6 vs the f64 oracle on the full 12-layer shape (tests/test_encoder_gpu.py), "
+                             "north_star tolerance 1e-4)"
+                      }[args.precision],
             "data": "synthetic (seeded token ids / unit vectors; random-init N(0,0.02) weights of the named shape)",
             "config": {
                 "workload": "BASELINE configs[2]: 1M-chunk corpus, bge-base-en-v1.5 shape (L12 H768 CLS) dense + "
@@ -376,15 +385,17 @@ def main():
             # f32: algorithmic FLOP against the f32-MFMA peak. f16x3: every algorithmic multiply-add is
             # three f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOP/s is the dense f16 peak / 3.
             "roofline": {
-                "kernel": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.precision == "f32" else
-                          "vr::gemm_f16x3_256_kernel (v_mfma_f32_32x32x16_f16, 3 passes per product; 256x256 tiles)",
+                "kernel": {"f32": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                           "f16x3": "vr::gemm_f16x3_256_kernel<EPI, 3> (v_mfma_f32_32x32x16_f16, 3 passes per "
+                                    "product; 256x256 tiles)",
+                           "f16": "vr::gemm_f16x3_256_kernel<EPI, 1> (v_mfma_f32_32x32x16_f16, one pass; "
+                                  "256x256x64 tiles)"}[args.precision],
                 "bound": "mfma",
                 "achieved": round(gemm_tf, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else round(PEAK_F16_MFMA_TFLOPS / 3.0, 1),
+                "peak": gemm_peak,
                 "unit": "TFLOP/s",
-                "frac": round(gemm_tf / (PEAK_F32_MFMA_TFLOPS if args.precision == "f32"
-                                         else PEAK_F16_MFMA_TFLOPS / 3.0), 4),
-                "executed_mfma_TFLOPs": round(gemm_tf * (1 if args.precision == "f32" else 3), 1),
+                "frac": round(gemm_tf / gemm_peak, 4),
+                "executed_mfma_TFLOPs": round(gemm_tf * (3 if args.precision == "f16x3" else 1), 1),
                 "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "f32" else "gemm_f16x3_256_kernel"),
                 "algorithmic_flop_per_launch": round(gemm_flop / max(gemm_n, 1)),
                 "launches": gemm_n,

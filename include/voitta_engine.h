@@ -122,7 +122,7 @@ typedef struct vr_bert_desc {
   int32_t pooling;       /* VR_POOL_MEAN | VR_POOL_CLS (sentence-transformers Pooling module) */
   int32_t normalize;     /* 1 = L2-normalise (sentence-transformers Normalize module) */
   float   eps;           /* layer_norm_eps */
-  int32_t precision;     /* VR_PRECISION_F32 | VR_PRECISION_F16X3 */
+  int32_t precision;     /* VR_PRECISION_F32 | VR_PRECISION_F16X3 | VR_PRECISION_F16 */
 } vr_bert_desc;
 
 /* arithmetic of the encoder's matrix products:
@@ -130,9 +130,13 @@ typedef struct vr_bert_desc {
  *   F16X3  operands carried as (hi, lo) f16 pairs (22 significant bits), three f16-MFMA passes per
  *          product into an f32 accumulator — f32-class accuracy (measured |1-cos| < 1e-6 against
  *          the f32 path) at 16/3 of the f32-MFMA rate. Activations beyond f16's range (65504) are
- *          clamped. Attention, LayerNorm, GELU, pooling stay f32 in both modes. */
+ *          clamped. Attention, LayerNorm, GELU, pooling stay f32 in both modes.
+ *   F16    operands rounded to f16 (weights pre-scaled by a power of two per tensor), one f16-MFMA pass,
+ *          f32 accumulate; everything outside the matrix products stays f32. Measured |1-cos| vs the
+ *          f64 oracle: see tests/test_encoder_gpu.py (north_star tolerance: 1e-4). */
 #define VR_PRECISION_F32   0
 #define VR_PRECISION_F16X3 1
+#define VR_PRECISION_F16   2
 
 /* tensors: 5 + 16*layers f32 arrays in `mem`, HF BertModel state-dict order and [out,in] layout:
  *   word_embeddings, position_embeddings, token_type_embeddings, embeddings.LayerNorm.{weight,bias},

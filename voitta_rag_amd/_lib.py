@@ -63,6 +63,7 @@ class VrBertDesc(C.Structure):
 
 VR_PRECISION_F32 = 0
 VR_PRECISION_F16X3 = 1
+VR_PRECISION_F16 = 2
 VR_POOL_MEAN = 0
 VR_POOL_CLS = 1
 VR_MEM_HOST = 0

@@ -141,8 +141,12 @@ __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs,
         half2_t h, l;
         split_f16(o.x, h.x, l.x);
         split_f16(o.y, h.y, l.y);
-        *reinterpret_cast<half2_t*>(out_hi + split_at(e)) = h;
-        *reinterpret_cast<half2_t*>(out_lo + split_at(e)) = l;
+        if (out_lo) {  // interleaved (hi, lo) row
+          *reinterpret_cast<half2_t*>(out_hi + split_at(e)) = h;
+          *reinterpret_cast<half2_t*>(out_lo + split_at(e)) = l;
+        } else {       // plain f16 row (VR_PRECISION_F16)
+          *reinterpret_cast<half2_t*>(out_hi + e) = h;
+        }
       }
     }
 }
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       v[i].y = w.y + pp.y + tt.y;
     }
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + 2 * o : nullptr, x_lo ? x_lo + 2 * o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + (x_lo ? 2 : 1) * o : nullptr, x_lo ? x_lo + 2 * o : nullptr);
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int T, int H,
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < kMaxPairs; ++i)
     if (i < pairs) v[i] = *reinterpret_cast<const float2*>(in + static_cast<int64_t>(t) * H + (i * 64 + lane) * 2);
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + 2 * o : nullptr, out_lo ? out_lo + 2 * o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + (out_lo ? 2 : 1) * o : nullptr, out_lo ? out_lo + 2 * o : nullptr);
 }
 
 // one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
@@ -620,7 +624,10 @@ __device__ __forceinline__ void glds16(const half_t* src, half_t* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int EPI>
+// PASSES = 3: split operands, interleaved (hi, lo) rows of 2K halfs (split_at), 32-deep K-tiles.
+// PASSES = 1: plain f16 operands (VR_PRECISION_F16), rows of K halfs, 64-deep K-tiles. Either way a
+// K-tile of one row is one 128-byte line, so staging, swizzle and LDS image are the same code.
+template <int EPI, int PASSES>
 __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
     const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     float unscale, long long* __restrict__ stamps) {
   __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object of the kernel (a second one makes hipcc
                                            // drain the in-flight loads before every fragment read)
-  const int tiles_n = N / GBN;
+  const int tiles_n = (N + GBN - 1) / GBN;  // N may end inside the last column tile (rows clamped, stores guarded)
   const int tiles_m = (M + GBM - 1) / GBM;
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -656,27 +663,27 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   const int srow = lane >> 3;
   const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
   const int r0 = wave * 8 + srow;  // + 64 j
-  const int64_t K2 = 2 * static_cast<int64_t>(K);
+  const int64_t K2 = (PASSES == 3 ? 2 : 1) * static_cast<int64_t>(K);  // halfs per operand row
   const half_t* g_a0 = Ah + static_cast<int64_t>(min(bm + r0, M - 1)) * K2 + schunk;
   const half_t* g_a1 = Ah + static_cast<int64_t>(min(bm + r0 + 64, M - 1)) * K2 + schunk;
   const half_t* g_a2 = Ah + static_cast<int64_t>(min(bm + r0 + 128, M - 1)) * K2 + schunk;
   const half_t* g_a3 = Ah + static_cast<int64_t>(min(bm + r0 + 192, M - 1)) * K2 + schunk;
-  const half_t* g_w0 = Wh + static_cast<int64_t>(bn + r0) * K2 + schunk;
-  const half_t* g_w1 = Wh + static_cast<int64_t>(bn + r0 + 64) * K2 + schunk;
-  const half_t* g_w2 = Wh + static_cast<int64_t>(bn + r0 + 128) * K2 + schunk;
-  const half_t* g_w3 = Wh + static_cast<int64_t>(bn + r0 + 192) * K2 + schunk;
+  const half_t* g_w0 = Wh + static_cast<int64_t>(min(bn + r0, N - 1)) * K2 + schunk;
+  const half_t* g_w1 = Wh + static_cast<int64_t>(min(bn + r0 + 64, N - 1)) * K2 + schunk;
+  const half_t* g_w2 = Wh + static_cast<int64_t>(min(bn + r0 + 128, N - 1)) * K2 + schunk;
+  const half_t* g_w3 = Wh + static_cast<int64_t>(min(bn + r0 + 192, N - 1)) * K2 + schunk;
   half_t* l_dst = lds + wave * 8 * 64;  // rows of 64 halfs (128 B); the W image starts at 256 * 64
 #define VR_GLDS_STAGE(buf, k0)                                          \
   do {                                                                  \
     half_t* d = l_dst + (buf) * kStageHalfs;                            \
-    glds16(g_a0 + 2 * (k0), d);                                         \
-    glds16(g_a1 + 2 * (k0), d + 64 * 64);                               \
-    glds16(g_a2 + 2 * (k0), d + 128 * 64);                              \
-    glds16(g_a3 + 2 * (k0), d + 192 * 64);                              \
-    glds16(g_w0 + 2 * (k0), d + 256 * 64);                              \
-    glds16(g_w1 + 2 * (k0), d + 256 * 64 + 64 * 64);                    \
-    glds16(g_w2 + 2 * (k0), d + 256 * 64 + 128 * 64);                   \
-    glds16(g_w3 + 2 * (k0), d + 256 * 64 + 192 * 64);                   \
+    glds16(g_a0 + (k0), d);                                         \
+    glds16(g_a1 + (k0), d + 64 * 64);                               \
+    glds16(g_a2 + (k0), d + 128 * 64);                              \
+    glds16(g_a3 + (k0), d + 192 * 64);                              \
+    glds16(g_w0 + (k0), d + 256 * 64);                              \
+    glds16(g_w1 + (k0), d + 256 * 64 + 64 * 64);                    \
+    glds16(g_w2 + (k0), d + 256 * 64 + 128 * 64);                   \
+    glds16(g_w3 + (k0), d + 256 * 64 + 192 * 64);                   \
   } while (0)
 
   f32x16 acc[4][2];
@@ -687,16 +694,17 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // fragments: lane l supplies row (l & 31), k = 8*(l >> 5) + j of a 16-deep step: k8-group
-  // g = 2*kk + (l >> 5), whose hi is chunk 2g and lo chunk 2g + 1 of the row's line
+  // fragments: lane l supplies row (l & 31), k = 8*(l >> 5) + j of a 16-deep step.
+  // PASSES 3: k8-group g = 2*kk + (l >> 5) of the 32-deep tile, hi = chunk 2g, lo = chunk 2g + 1.
+  // PASSES 1: chunk 2*kk + (l >> 5) of the 64-deep tile.
   const int frow = lane & 31;
   const int fsw = (frow >> 1) & 7;
-  const int fh0 = ((2 * (lane >> 5)) ^ fsw) * 8, fl0 = ((2 * (lane >> 5) + 1) ^ fsw) * 8;          // k-step 0
-  const int fh1 = ((2 * (2 + (lane >> 5))) ^ fsw) * 8, fl1 = ((2 * (2 + (lane >> 5)) + 1) ^ fsw) * 8;  // k-step 1
+  const int fhalf = lane >> 5;
   const int pa = (wm * 128 + frow) * 64;
   const int pw = 256 * 64 + (wn * 64 + frow) * 64;
 
-  const int nk = K / GBK;
+  constexpr int kTileHalfs = 64;               // halfs of one row per K-tile: 32 k x (hi, lo) or 64 k
+  const int nk = K / (PASSES == 3 ? 32 : 64);
   long long t_start = 0, t_loop = 0, t_epi = 0;
   if (stamps) t_start = __builtin_amdgcn_s_memtime();
   VR_GLDS_STAGE(0, 0);
@@ -707,34 +715,45 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     const half_t* st = lds + (kt & 1) * kStageHalfs;
     // A direct-to-LDS load holds the issuing wave for ~100+ cycles. Eight of them in a row at the top
     // of the K-tile left the matrix pipe idle for a third of it; instead one load is issued after
-    // every six MFMAs (one row of MFMA tiles), where the partner wave of the SIMD fills the gap.
+    // every row of MFMA tiles, where the partner wave of the SIMD fills the gap.
     // (the last K-tile re-loads tile 0 into the idle stage instead of branching around every load:
     //  nothing reads it, and the vmcnt(0) + barrier below retire it before the epilogue reuses LDS)
     half_t* nd = l_dst + ((kt + 1) & 1) * kStageHalfs;
-    const int nk0 = kt + 1 < nk ? 2 * (kt + 1) * GBK : 0;
+    const int nk0 = kt + 1 < nk ? (kt + 1) * kTileHalfs : 0;
+    constexpr int kSteps = PASSES == 3 ? 2 : 4;  // 16-deep MFMA steps per K-tile
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int fh = kk ? fh1 : fh0, fl = kk ? fl1 : fl0;
+    for (int kk = 0; kk < kSteps; ++kk) {
       f16x8 ah[4], al[4], wh[2], wl[2];
+      if (PASSES == 3) {
+        const int fh = ((2 * (2 * kk + fhalf)) ^ fsw) * 8, fl = ((2 * (2 * kk + fhalf) + 1) ^ fsw) * 8;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
-        wl[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fl);
-      }
+        for (int j = 0; j < 2; ++j) {
+          wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
+          wl[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fl);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
-        al[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fl);
+        for (int i = 0; i < 4; ++i) {
+          ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
+          al[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fl);
+        }
+      } else {
+        const int fh = ((2 * kk + fhalf) ^ fsw) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+          if (PASSES == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+          }
         }
-        {
+        if (kk < 2) {
           const int piece = kk * 4 + i;  // compile-time after unrolling
           const half_t* src = piece == 0 ? g_a0 : piece == 1 ? g_a1 : piece == 2 ? g_a2 : piece == 3 ? g_a3
                             : piece == 4 ? g_w0 : piece == 5 ? g_w1 : piece == 6 ? g_w2 : g_w3;
@@ -757,13 +776,14 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SLD);
   const int c4 = (lane & 15) * 4;
   const int gcol = bn + wn * 64 + c4;
-  const float4 b4 = *reinterpret_cast<const float4*>(bias + gcol);
+  const bool col_ok = gcol < N;  // N % 4 == 0: a lane's four columns are in or out together
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + (col_ok ? gcol : 0));
   float4 r4[2][8];  // residual rows of the current tile and of the next one (requested a tile ahead)
   if (EPI == EPI_BIAS_RESIDUAL) {
 #pragma unroll
     for (int it = 0; it < 8; ++it)
       r4[0][it] = *reinterpret_cast<const float4*>(
-          R + static_cast<int64_t>(min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1)) * N + gcol);
+          R + static_cast<int64_t>(min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1)) * N + (col_ok ? gcol : 0));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -772,7 +792,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #pragma unroll
       for (int it = 0; it < 8; ++it)
         r4[(i + 1) & 1][it] = *reinterpret_cast<const float4*>(
-            R + static_cast<int64_t>(min(row0 + 32 + 4 * it, M - 1)) * N + gcol);
+            R + static_cast<int64_t>(min(row0 + 32 + 4 * it, M - 1)) * N + (col_ok ? gcol : 0));
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -785,7 +805,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
       const int lr = it * 4 + (lane >> 4);
       const int grow = row0 + 4 * it;
       float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
-      if (grow >= M) return;
+      if (grow >= M || !col_ok) return;
       v.x = v.x * unscale + b4.x;
       v.y = v.y * unscale + b4.y;
       v.z = v.z * unscale + b4.z;
@@ -799,9 +819,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
           g[c] = gelu_fast(g[c]);
           split_f16(g[c], h[c], l[c]);
         }
-        const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
-        *reinterpret_cast<uint2*>(Ch + so) = *reinterpret_cast<const uint2*>(h);
-        *reinterpret_cast<uint2*>(Cl + so) = *reinterpret_cast<const uint2*>(l);
+        if (PASSES == 3) {
+          const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
+          *reinterpret_cast<uint2*>(Ch + so) = *reinterpret_cast<const uint2*>(h);
+          *reinterpret_cast<uint2*>(Cl + so) = *reinterpret_cast<const uint2*>(l);
+        } else {
+          *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);  // plain f16 rows
+        }
       } else {
         if (EPI == EPI_BIAS_RESIDUAL) {
           v.x += r4[i & 1][it].x;
@@ -852,40 +876,56 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int
   if (i < n) {
     half_t h, l;
     split_f16(w[i] * scale, h, l);
-    const int64_t o = (i / K) * (2 * K) + split_at(static_cast<int>(i % K));  // interleaved layout, see split_at
-    hi[o] = h;
-    lo[o] = l;
+    if (lo) {
+      const int64_t o = (i / K) * (2 * K) + split_at(static_cast<int>(i % K));  // interleaved layout, see split_at
+      hi[o] = h;
+      lo[o] = l;
+    } else {
+      hi[i] = h;  // plain f16 rows (VR_PRECISION_F16)
+    }
   }
 }
 
+template <int PASSES>
+static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Al, const half_t* Wh,
+                       const half_t* Wl, const float* bias, const float* R, float* C, half_t* Ch, half_t* Cl, int M,
+                       int N, int K, float unscale, long long* stamps) {
+  switch (epi) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R,
+                         C, Ch, Cl, M, N, K, unscale, stamps);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_GELU, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
+                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_RESIDUAL, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
+                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+      break;
+  }
+}
+
+// passes = 3: operands are interleaved (hi, lo) rows (Al = Ah + 8, Wl = Wh + 8); passes = 1: plain f16
+// rows, Al / Wl / Cl unused.
 static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half_t* Al, const half_t* Wh,
                              const half_t* Wl, float unscale, const float* bias, const float* R, float* C,
-                             half_t* Ch, half_t* Cl, int M, int N, int K) {
-  VR_CHECK(N % HBN_ == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d must be multiples of %d / %d", N, K, HBN_, HBK_);
+                             half_t* Ch, half_t* Cl, int M, int N, int K, int passes = 3) {
+  VR_CHECK(N % 4 == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d: N must be a multiple of 4, K of %d", N, K, HBK_);
   if (M <= 0) return 0;
   hipStream_t s = e->stream;
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
-  if (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128) {
-    const int grid256 = ((M + GBM - 1) / GBM) * (N / GBN);
+  if (passes == 1 || (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128)) {
+    const int grid256 = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     static const bool want_stamps = getenv("VR_GEMM_STAMPS") != nullptr;  // diagnostics: phase lengths per block
     static int stamp_prints = 0;
     long long* stamps = nullptr;
     if (want_stamps && stamp_prints < 12) VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), sizeof(long long) * 4 * grid256));
-    switch (epi) {
-      case EPI_BIAS:
-        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R,
-                           C, Ch, Cl, M, N, K, unscale, stamps);
-        break;
-      case EPI_BIAS_GELU:
-        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_GELU>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl,
-                           bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
-        break;
-      default:
-        hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_RESIDUAL>), dim3(grid256), dim3(512), 0, s, Ah, Al, Wh, Wl,
-                           bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
-        break;
-    }
+    if (passes == 1)
+      launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+    else
+      launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
     prof_end(e);
     if (stamps) {
       std::vector<long long> h(static_cast<size_t>(4) * grid256);
@@ -893,19 +933,19 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
       VR_HIP(hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
       (void)hipFree(stamps);
       double p = 0, l = 0, ep = 0;
-      long long t0 = h[3], t1 = h[3];
       for (int b = 0; b < grid256; ++b) {
         p += h[4 * b]; l += h[4 * b + 1]; ep += h[4 * b + 2];
-        t0 = std::min(t0, h[4 * b + 3]); t1 = std::max(t1, h[4 * b + 3] + h[4 * b] + h[4 * b + 1] + h[4 * b + 2]);
       }
-      fprintf(stderr, "[gemm256 epi=%d M=%d N=%d K=%d] blocks %d: prologue %.0f  loop %.0f (%.0f / K-tile)  epilogue %.0f cycles; "
-              "kernel span %lld cycles\n", epi, M, N, K, grid256, p / grid256, l / grid256, l / grid256 / (K / GBK), ep / grid256,
-              t1 - t0);
+      const int ktile = passes == 1 ? 64 : 32;
+      fprintf(stderr, "[gemm256 passes=%d epi=%d M=%d N=%d K=%d] blocks %d: prologue %.0f  loop %.0f (%.0f / K-tile)  "
+              "epilogue %.0f cycles\n", passes, epi, M, N, K, grid256, p / grid256, l / grid256, l / grid256 / (K / ktile),
+              ep / grid256);
       ++stamp_prints;
     }
     VR_HIP(hipGetLastError());
     return 0;
   }
+  VR_CHECK(N % HBN_ == 0, "GEMM shape N=%d must be a multiple of %d", N, HBN_);
   const int grid = ((M + HBM_ - 1) / HBM_) * (N / HBN_);
   switch (epi) {
     case EPI_BIAS:
@@ -1048,9 +1088,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         split_f16(v.y, h[1], lo[1]);
         split_f16(v.z, h[2], lo[2]);
         split_f16(v.w, h[3], lo[3]);
-        const int64_t so = static_cast<int64_t>(t0 + q_tok) * (2 * H) + split_at(head * DH + 4 * g + 16 * s);
-        *reinterpret_cast<uint2*>(ctx_hi + so) = *reinterpret_cast<const uint2*>(h);
-        *reinterpret_cast<uint2*>(ctx_lo + so) = *reinterpret_cast<const uint2*>(lo);
+        if (ctx_lo) {
+          const int64_t so = static_cast<int64_t>(t0 + q_tok) * (2 * H) + split_at(head * DH + 4 * g + 16 * s);
+          *reinterpret_cast<uint2*>(ctx_hi + so) = *reinterpret_cast<const uint2*>(h);
+          *reinterpret_cast<uint2*>(ctx_lo + so) = *reinterpret_cast<const uint2*>(lo);
+        } else {  // plain f16 rows (VR_PRECISION_F16)
+          *reinterpret_cast<uint2*>(ctx_hi + off + 16 * s) = *reinterpret_cast<const uint2*>(h);
+        }
       } else {
         *reinterpret_cast<float4*>(ctx + off + 16 * s) = v;
       }
@@ -1072,7 +1116,7 @@ static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_
 }
 
 // w (device, n floats) -> scaled (hi, lo) f16 pair; scale = 2^s puts max|w| into [1024, 2048)
-static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, int K, SplitWeight* out) {
+static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, int K, bool plain, SplitWeight* out) {
   float* scratch = nullptr;
   VR_TRY(dev_alloc_copy(e, enc, nullptr, 1, 0, &scratch));
   VR_HIP(hipMemsetAsync(scratch, 0, sizeof(float), e->stream));
@@ -1091,10 +1135,10 @@ static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, 
   }
   const float scale = std::ldexp(1.0f, s);
   out->unscale = std::ldexp(1.0f, -s);
-  float* both = nullptr;  // one interleaved array of 2n halfs (= n floats), see split_at
-  VR_TRY(dev_alloc_copy(e, enc, nullptr, n, 0, &both));
+  float* both = nullptr;  // one interleaved array of 2n halfs (= n floats), see split_at; plain: n halfs
+  VR_TRY(dev_alloc_copy(e, enc, nullptr, plain ? (n + 1) / 2 : n, 0, &both));
   out->hi = reinterpret_cast<_Float16*>(both);
-  out->lo = out->hi + 8;
+  out->lo = plain ? nullptr : out->hi + 8;
   hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream,
                      w_dev, static_cast<int64_t>(n), K, scale, out->hi, out->lo);
   VR_HIP(hipGetLastError());
@@ -1126,8 +1170,8 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
            "head size %d unsupported (32 or 64)", d->heads ? H / d->heads : 0);
   VR_CHECK(n_tensors == 5 + 16 * L, "expected %d tensors, got %d", 5 + 16 * L, n_tensors);
   VR_CHECK(d->pooling == 0 || d->pooling == 1, "pooling must be 0 (mean) or 1 (cls)");
-  VR_CHECK(d->precision == VR_PRECISION_F32 || d->precision == VR_PRECISION_F16X3, "unknown precision %d",
-           d->precision);
+  VR_CHECK(d->precision == VR_PRECISION_F32 || d->precision == VR_PRECISION_F16X3 || d->precision == VR_PRECISION_F16,
+           "unknown precision %d", d->precision);
   for (int i = 0; i < n_tensors; ++i) VR_CHECK(t[i] != nullptr, "tensor %d is null", i);
   encoder_release(e);
   Encoder* enc = new Encoder();
@@ -1159,11 +1203,12 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
     VR_TRY(dev_alloc_copy(e, enc, w[13], H, mem, &lw.b2));
     VR_TRY(dev_alloc_copy(e, enc, w[14], H, mem, &lw.ln2g));
     VR_TRY(dev_alloc_copy(e, enc, w[15], H, mem, &lw.ln2b));
-    if (d->precision == VR_PRECISION_F16X3) {
-      VR_TRY(make_split(e, enc, lw.wqkv, 3 * HH, H, &lw.s_qkv));
-      VR_TRY(make_split(e, enc, lw.wo, HH, H, &lw.s_o));
-      VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, H, &lw.s_1));
-      VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, I, &lw.s_2));
+    if (d->precision != VR_PRECISION_F32) {
+      const bool plain = d->precision == VR_PRECISION_F16;
+      VR_TRY(make_split(e, enc, lw.wqkv, 3 * HH, H, plain, &lw.s_qkv));
+      VR_TRY(make_split(e, enc, lw.wo, HH, H, plain, &lw.s_o));
+      VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, H, plain, &lw.s_1));
+      VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, I, plain, &lw.s_2));
     }
     enc->layers.push_back(lw);
   }
@@ -1188,7 +1233,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->ctx));
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->tmp));
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * I, 0, &enc->ffn));
-  if (enc->d.precision == VR_PRECISION_F16X3) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->xs));
+  if (enc->d.precision != VR_PRECISION_F32) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->xs));
   enc->ws_tokens = tokens;
   return 0;
 }
@@ -1203,13 +1248,16 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   const unsigned row_blocks = static_cast<unsigned>((T + 3) / 4);
   // f16x3 mode: every GEMM input also exists as (hi, lo) f16. The split hidden state lives in xs;
   // the context and the FFN intermediate are ONLY needed split, so they reuse the f32 buffers.
-  const bool split = d.precision == VR_PRECISION_F16X3;
+  // f16 mode: the same, with plain f16 rows and no lo half (the lo pointers are null).
+  const bool split = d.precision != VR_PRECISION_F32;
+  const bool plain = d.precision == VR_PRECISION_F16;
+  const int passes = plain ? 1 : 3;
   half_t* xh = split ? reinterpret_cast<half_t*>(enc->xs) : nullptr;
-  half_t* xl = split ? xh + 8 : nullptr;  // interleaved (hi, lo) layout, see split_at
+  half_t* xl = split && !plain ? xh + 8 : nullptr;  // interleaved (hi, lo) layout, see split_at
   half_t* ch = split ? reinterpret_cast<half_t*>(enc->ctx) : nullptr;
-  half_t* cl = split ? ch + 8 : nullptr;
+  half_t* cl = split && !plain ? ch + 8 : nullptr;
   half_t* fh = split ? reinterpret_cast<half_t*>(enc->ffn) : nullptr;
-  half_t* fl = split ? fh + 8 : nullptr;
+  half_t* fl = split && !plain ? fh + 8 : nullptr;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
                      enc->x, xh, xl);
@@ -1235,7 +1283,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     const bool tail = cls_tail && li + 1 == enc->layers.size();
     if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
-                               enc->qkv, nullptr, nullptr, T, 3 * H, H));
+                               enc->qkv, nullptr, nullptr, T, 3 * H, H, passes));
     else
       VR_TRY(launch_gemm(e, EPI_BIAS, enc->x, w.wqkv, w.bqkv, nullptr, enc->qkv, T, 3 * H, H));
     const int qb = tail ? 1 : qblocks;  // tail: only the query block that holds token 0 of every sequence
@@ -1252,24 +1300,24 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       const unsigned gblocks = static_cast<unsigned>((n_seq + 3) / 4);
       const unsigned cblocks = gblocks;
       hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->ctx),
-                         cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(ctxc));
+                         cu_dev, seq0, tok_base, n_seq, T, plain ? H / 8 : H / 4, reinterpret_cast<float4*>(ctxc));
       hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->x),
                          cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(xc));
       half_t* xch = reinterpret_cast<half_t*>(xsc);
       half_t* cch = reinterpret_cast<half_t*>(ctxc);
       half_t* fch = reinterpret_cast<half_t*>(ffnc);
       if (split)
-        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, cch, cch + 8, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, xc, tmpc,
-                                 nullptr, nullptr, n_seq, H, H));
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, cch, plain ? nullptr : cch + 8, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, xc, tmpc,
+                                 nullptr, nullptr, n_seq, H, H, passes));
       else
         VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ctxc, w.wo, w.bo, xc, tmpc, n_seq, H, H));
       hipLaunchKernelGGL(layernorm_kernel, dim3(cblocks), dim3(256), 0, s, tmpc, n_seq, H, w.ln1g, w.ln1b, d.eps, xc,
-                         split ? xch : nullptr, split ? xch + 8 : nullptr);
+                         split ? xch : nullptr, split && !plain ? xch + 8 : nullptr);
       if (split) {
-        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xch, xch + 8, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr, nullptr,
-                                 fch, fch + 8, n_seq, I, H));
-        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, fch, fch + 8, w.s_2.hi, w.s_2.lo, w.s_2.unscale, w.b2, xc, tmpc,
-                                 nullptr, nullptr, n_seq, H, I));
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xch, plain ? nullptr : xch + 8, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr, nullptr,
+                                 fch, plain ? nullptr : fch + 8, n_seq, I, H, passes));
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, fch, plain ? nullptr : fch + 8, w.s_2.hi, w.s_2.lo, w.s_2.unscale, w.b2, xc, tmpc,
+                                 nullptr, nullptr, n_seq, H, I, passes));
       } else {
         VR_TRY(launch_gemm(e, EPI_BIAS_GELU, xc, w.w1, w.b1, nullptr, ffnc, n_seq, I, H));
         VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ffnc, w.w2, w.b2, xc, tmpc, n_seq, H, I));
@@ -1283,16 +1331,16 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     }
     if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, ch, cl, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, enc->x,
-                               enc->tmp, nullptr, nullptr, T, H, H));
+                               enc->tmp, nullptr, nullptr, T, H, H, passes));
     else
       VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln1g, w.ln1b,
                        d.eps, enc->x, xh, xl);
     if (split) {
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, xl, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr,
-                               nullptr, fh, fl, T, I, H));
+                               nullptr, fh, fl, T, I, H, passes));
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, fh, fl, w.s_2.hi, w.s_2.lo, w.s_2.unscale, w.b2, enc->x,
-                               enc->tmp, nullptr, nullptr, T, H, I));
+                               enc->tmp, nullptr, nullptr, T, H, I, passes));
     } else {
       VR_TRY(launch_gemm(e, EPI_BIAS_GELU, enc->x, w.w1, w.b1, nullptr, enc->ffn, T, I, H));
       VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));

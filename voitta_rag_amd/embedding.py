@@ -71,9 +71,10 @@ class NativeSentenceEncoder:
                              vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"],
                              type_vocab=cfg.get("type_vocab_size", 2), pooling=pooling, normalize=normalize,
                              eps=cfg.get("layer_norm_eps", 1e-12),
-                             # f16x3 (default): (hi, lo) f16 operands, three MFMA passes — 22 significant
-                             # bits, |1 - cos| ~5e-8 vs f64, 2.6x the throughput of the f32-input MFMA path
-                             precision=os.environ.get("VOITTA_ENCODER_PRECISION", "f16x3"))
+                             # f16 (default): f16 MFMA operands, f32 accumulate, |1 - cos| < 1e-6 vs f64
+                             # (north_star allows 1e-4); f16x3: (hi, lo) f16 operands, three passes,
+                             # |1 - cos| ~5e-8, 1.8x slower; f32: the f32-input MFMA, 5x slower
+                             precision=os.environ.get("VOITTA_ENCODER_PRECISION", "f16"))
         return cls(engine or get_engine(), desc, cls._load_weights(path), cls._load_tokenizer(path, cfg), max_seq)
 
     @staticmethod

@@ -55,9 +55,10 @@ class BertDesc:
         d.pooling = VR_POOL_CLS if self.pooling == "cls" else VR_POOL_MEAN
         d.normalize = int(self.normalize)
         d.eps = self.eps
-        if self.precision not in ("f32", "f16x3"):
+        codes = {"f32": _lib.VR_PRECISION_F32, "f16x3": _lib.VR_PRECISION_F16X3, "f16": _lib.VR_PRECISION_F16}
+        if self.precision not in codes:
             raise ValueError(f"unknown encoder precision {self.precision!r}")
-        d.precision = _lib.VR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.VR_PRECISION_F32
+        d.precision = codes[self.precision]
         return d
 
 
