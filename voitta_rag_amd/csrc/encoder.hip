@@ -1102,6 +1102,141 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// The same attention on the f16 matrix pipe (VR_PRECISION_F16): Q (pre-scaled by 1/sqrt(d_h)), K, V and
+// the probabilities P are rounded to f16, every product accumulates in f32, the softmax stays f32.
+// v_mfma_f32_16x16x32_f16 has the C layout of the 16x16x4 instruction, so the structure above
+// carries over: S^T = K Q^T leaves lane (q, g) with the logits of keys 16t + 4g + r — and the B
+// operand of O^T += V^T P^T wants 8 k-slots per lane, so a 32-key step takes its slots in the order
+// (g, tile parity, r): slot 8g + 4b + r = key 32u + 16b + 4g + r. V is staged TRANSPOSED in that
+// order (sVt[d][slot]), so its A fragments are plain 16-byte reads. 16 MFMAs of 16 cycles per 64
+// keys against 128 of 32 cycles in the f32 kernel: the kernel is bound by the softmax's VALU work.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_f16_kernel(const float* __restrict__ qkv,
+                                                            const int32_t* __restrict__ cu, int seq0,
+                                                            int tok_base, int H, int qblocks, float scale,
+                                                            half_t* __restrict__ ctx_h) {
+  constexpr int LDK = DH + 8;   // halfs per staged K row
+  constexpr int LDV = 64 + 8;   // halfs per staged V^T row (64 key slots)
+  constexpr int NS = DH / 16;   // 16-wide d blocks of the output
+  constexpr int NKB = DH / 32;  // 32-deep MFMA steps over d
+  __shared__ half_t sK[64 * LDK];
+  __shared__ half_t sVt[DH * LDV];
+  const int seq = seq0 + blockIdx.x / qblocks;
+  const int qb = blockIdx.x % qblocks;
+  const int head = blockIdx.y;
+  const int t0 = cu[seq] - tok_base;
+  const int len = cu[seq + 1] - cu[seq];
+  if (qb * 64 >= len) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int q_tok = qb * 64 + wave * 16 + qi;
+  const bool q_valid = q_tok < len;
+  const int64_t row3 = 3 * static_cast<int64_t>(H);
+
+  f16x8 qf[NKB];
+  {
+    const float* qp = qkv + (t0 + (q_valid ? q_tok : len - 1)) * row3 + head * DH + 8 * g;
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + 32 * u);
+      const float4 b = *reinterpret_cast<const float4*>(qp + 32 * u + 4);
+      qf[u] = f16x8{static_cast<half_t>(a.x * scale), static_cast<half_t>(a.y * scale), static_cast<half_t>(a.z * scale),
+                    static_cast<half_t>(a.w * scale), static_cast<half_t>(b.x * scale), static_cast<half_t>(b.y * scale),
+                    static_cast<half_t>(b.z * scale), static_cast<half_t>(b.w * scale)};
+    }
+  }
+  f32x4 o[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -__builtin_inff();
+  float l = 0.0f;
+
+  for (int kt = 0; kt < len; kt += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (DH / 4); idx += 256) {
+      const int key = idx / (DH / 4), c4 = idx % (DH / 4);
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (kt + key < len) {
+        const float* p = qkv + (t0 + kt + key) * row3 + H + head * DH + c4 * 4;
+        kv = *reinterpret_cast<const float4*>(p);
+        vv = *reinterpret_cast<const float4*>(p + H);
+      }
+      half_t kh[4] = {static_cast<half_t>(kv.x), static_cast<half_t>(kv.y), static_cast<half_t>(kv.z),
+                      static_cast<half_t>(kv.w)};
+      *reinterpret_cast<uint2*>(sK + key * LDK + c4 * 4) = *reinterpret_cast<const uint2*>(kh);
+      // key = 32u + 16b + 4g' + r  ->  slot 32u + 8g' + 4b + r
+      const int slot = (key & 32) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
+      sVt[(c4 * 4 + 0) * LDV + slot] = static_cast<half_t>(vv.x);
+      sVt[(c4 * 4 + 1) * LDV + slot] = static_cast<half_t>(vv.y);
+      sVt[(c4 * 4 + 2) * LDV + slot] = static_cast<half_t>(vv.z);
+      sVt[(c4 * 4 + 3) * LDV + slot] = static_cast<half_t>(vv.w);
+    }
+    __syncthreads();
+
+    f32x4 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NKB; ++u) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + (t * 16 + qi) * LDK + 32 * u + 8 * g);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u], st[t], 0, 0, 0);
+      }
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt + t * 16 + 4 * g + r;
+        const float v = key < len ? st[t][r] : -__builtin_inff();
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);  // finite: key kt < len is always valid
+    const float alpha = expf(m - m_new);
+    float psum = 0.0f;
+    f16x8 pb[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(st[t][r] - m_new);
+        psum += p;
+        pb[t >> 1][(t & 1) * 4 + r] = static_cast<half_t>(p);
+      }
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(sVt + (16 * s + qi) * LDV + 32 * u + 8 * g);
+        o[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u], o[s], 0, 0, 0);
+      }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (q_valid) {
+    const float inv = 1.0f / l;
+    const int64_t off = static_cast<int64_t>(t0 + q_tok) * H + head * DH + 4 * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      half_t h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = static_cast<half_t>(fminf(fmaxf(o[s][r] * inv, -65504.0f), 65504.0f));
+      *reinterpret_cast<uint2*>(ctx_h + off + 16 * s) = *reinterpret_cast<const uint2*>(h);
+    }
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 
 static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_floats, int mem, float** out) {
@@ -1289,7 +1424,13 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     const int qb = tail ? 1 : qblocks;  // tail: only the query block that holds token 0 of every sequence
     dim3 agrid(static_cast<unsigned>(n_seq * qb), static_cast<unsigned>(nh));
     prof_begin(e, VR_PROF_ATTENTION, tail ? attn_flop / qblocks : attn_flop);
-    if (dh == 64)
+    if (plain && dh == 64)
+      hipLaunchKernelGGL((attention_f16_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H, qb,
+                         scale, ch);
+    else if (plain)
+      hipLaunchKernelGGL((attention_f16_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H, qb,
+                         scale, ch);
+    else if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
                          qb, scale, enc->ctx, ch, cl);
     else
