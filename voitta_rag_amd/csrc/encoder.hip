@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gather_first_rows_kernel(const float4* __
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;  // padded LDS row (floats); rows stay 16-byte aligned
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3 };  // F16: plain f16 output (256-tile kernel only)
 
 // Linear tile id -> (row panel, column panel), row panels taken kGroupM at a time with the column
 // index slow inside a group. The ~32 blocks an XCD runs together then cover ~8 row panels x ~4
@@ -826,6 +826,12 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
         } else {
           *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);  // plain f16 rows
         }
+      } else if (EPI == EPI_BIAS_F16) {  // Q, K, V for the f16 attention kernel
+        half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
+                       static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
+                       static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
+                       static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
+        *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
       } else {
         if (EPI == EPI_BIAS_RESIDUAL) {
           v.x += r4[i & 1][it].x;
@@ -897,6 +903,10 @@ static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const
       break;
     case EPI_BIAS_GELU:
       hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_GELU, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
+                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+      break;
+    case EPI_BIAS_F16:
+      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_F16, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
                          bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
       break;
     default:
@@ -1111,7 +1121,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // order (sVt[d][slot]), so its A fragments are plain 16-byte reads. 16 MFMAs of 16 cycles per 64
 // keys against 128 of 32 cycles in the f32 kernel: the kernel is bound by the softmax's VALU work.
 template <int DH>
-__global__ __launch_bounds__(256) void attention_f16_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* __restrict__ qkv,
                                                             const int32_t* __restrict__ cu, int seq0,
                                                             int tok_base, int H, int qblocks, float scale,
                                                             half_t* __restrict__ ctx_h) {
@@ -1138,16 +1148,11 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const float* __restr
 
   f16x8 qf[NKB];
   {
-    const float* qp = qkv + (t0 + (q_valid ? q_tok : len - 1)) * row3 + head * DH + 8 * g;
+    const half_t* qp = qkv + (t0 + (q_valid ? q_tok : len - 1)) * row3 + head * DH + 8 * g;
 #pragma unroll
-    for (int u = 0; u < NKB; ++u) {
-      const float4 a = *reinterpret_cast<const float4*>(qp + 32 * u);
-      const float4 b = *reinterpret_cast<const float4*>(qp + 32 * u + 4);
-      qf[u] = f16x8{static_cast<half_t>(a.x * scale), static_cast<half_t>(a.y * scale), static_cast<half_t>(a.z * scale),
-                    static_cast<half_t>(a.w * scale), static_cast<half_t>(b.x * scale), static_cast<half_t>(b.y * scale),
-                    static_cast<half_t>(b.z * scale), static_cast<half_t>(b.w * scale)};
-    }
+    for (int u = 0; u < NKB; ++u) qf[u] = *reinterpret_cast<const f16x8*>(qp + 32 * u);
   }
+  const float scale2 = scale * 1.4426950408889634f;  // logits in the log2 domain: the softmax uses v_exp_f32 directly
   f32x4 o[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1156,23 +1161,20 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const float* __restr
 
   for (int kt = 0; kt < len; kt += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * (DH / 4); idx += 256) {
-      const int key = idx / (DH / 4), c4 = idx % (DH / 4);
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    for (int idx = tid; idx < 64 * (DH / 8); idx += 256) {
+      const int key = idx / (DH / 8), c8 = idx % (DH / 8);
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
       if (kt + key < len) {
-        const float* p = qkv + (t0 + kt + key) * row3 + H + head * DH + c4 * 4;
-        kv = *reinterpret_cast<const float4*>(p);
-        vv = *reinterpret_cast<const float4*>(p + H);
+        const half_t* p = qkv + (t0 + kt + key) * row3 + H + head * DH + c8 * 8;
+        kv = *reinterpret_cast<const uint4*>(p);
+        vv = *reinterpret_cast<const uint4*>(p + H);
       }
-      half_t kh[4] = {static_cast<half_t>(kv.x), static_cast<half_t>(kv.y), static_cast<half_t>(kv.z),
-                      static_cast<half_t>(kv.w)};
-      *reinterpret_cast<uint2*>(sK + key * LDK + c4 * 4) = *reinterpret_cast<const uint2*>(kh);
+      *reinterpret_cast<uint4*>(sK + key * LDK + c8 * 8) = kv;
       // key = 32u + 16b + 4g' + r  ->  slot 32u + 8g' + 4b + r
       const int slot = (key & 32) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
-      sVt[(c4 * 4 + 0) * LDV + slot] = static_cast<half_t>(vv.x);
-      sVt[(c4 * 4 + 1) * LDV + slot] = static_cast<half_t>(vv.y);
-      sVt[(c4 * 4 + 2) * LDV + slot] = static_cast<half_t>(vv.z);
-      sVt[(c4 * 4 + 3) * LDV + slot] = static_cast<half_t>(vv.w);
+      const half_t* vh = reinterpret_cast<const half_t*>(&vv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sVt[(c8 * 8 + i) * LDV + slot] = vh[i];
     }
     __syncthreads();
 
@@ -1192,21 +1194,21 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt + t * 16 + 4 * g + r;
-        const float v = key < len ? st[t][r] : -__builtin_inff();
+        const float v = key < len ? st[t][r] * scale2 : -__builtin_inff();
         st[t][r] = v;
         mx = fmaxf(mx, v);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);  // finite: key kt < len is always valid
-    const float alpha = expf(m - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     float psum = 0.0f;
     f16x8 pb[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = expf(st[t][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(st[t][r] - m_new);
         psum += p;
         pb[t >> 1][(t & 1) * 4 + r] = static_cast<half_t>(p);
       }
@@ -1416,7 +1418,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   for (size_t li = 0; li < enc->layers.size(); ++li) {
     const LayerWeights& w = enc->layers[li];
     const bool tail = cls_tail && li + 1 == enc->layers.size();
-    if (split)
+    if (plain)  // Q, K, V as plain f16 rows for attention_f16_kernel
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_F16, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
+                               nullptr, reinterpret_cast<half_t*>(enc->qkv), nullptr, T, 3 * H, H, passes));
+    else if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
                                enc->qkv, nullptr, nullptr, T, 3 * H, H, passes));
     else
@@ -1425,11 +1430,11 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     dim3 agrid(static_cast<unsigned>(n_seq * qb), static_cast<unsigned>(nh));
     prof_begin(e, VR_PROF_ATTENTION, tail ? attn_flop / qblocks : attn_flop);
     if (plain && dh == 64)
-      hipLaunchKernelGGL((attention_f16_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H, qb,
-                         scale, ch);
+      hipLaunchKernelGGL((attention_f16_kernel<64>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
+                         cu_dev, seq0, tok_base, H, qb, scale, ch);
     else if (plain)
-      hipLaunchKernelGGL((attention_f16_kernel<32>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H, qb,
-                         scale, ch);
+      hipLaunchKernelGGL((attention_f16_kernel<32>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
+                         cu_dev, seq0, tok_base, H, qb, scale, ch);
     else if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
                          qb, scale, enc->ctx, ch, cl);
