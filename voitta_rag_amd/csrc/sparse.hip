@@ -150,14 +150,43 @@ __global__ __launch_bounds__(64) void sell_build_kernel(const SliceDesc* __restr
   }
 }
 
-// +1 document frequency for every real entry of the freshly built slices
-__global__ void df_update_region_kernel(const int32_t* __restrict__ sidx, int64_t begin, int64_t end,
-                                        int32_t* keys, int32_t* cnt, int64_t cap, int32_t* distinct) {
-  int64_t i = begin + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < end) {
-    int32_t id = sidx[i];
-    if (id >= 0) df_add(keys, cnt, cap, id, 1, distinct);
+// +1 document frequency for every real entry of the freshly built slices. Term frequencies are
+// Zipfian: sent straight to the global table, the atomics of a batch pile up on a few hundred hot
+// counters (0.78 ms per 2048-chunk batch). Each block first counts its 4096 entries in an LDS hash
+// and then sends one global update per DISTINCT term it saw.
+constexpr int kDfChunk = 4096;  // entries per block
+constexpr int kDfSlots = 8192;  // LDS hash slots (load factor <= 0.5)
+
+__global__ __launch_bounds__(256) void df_update_region_kernel(const int32_t* __restrict__ sidx, int64_t begin,
+                                                               int64_t end, int32_t* keys, int32_t* cnt,
+                                                               int64_t cap, int32_t* distinct) {
+  __shared__ int32_t lk[kDfSlots];
+  __shared__ int32_t lc[kDfSlots];
+  for (int i = threadIdx.x; i < kDfSlots; i += 256) {
+    lk[i] = -1;
+    lc[i] = 0;
   }
+  __syncthreads();
+  const int64_t b0 = begin + static_cast<int64_t>(blockIdx.x) * kDfChunk;
+  const int64_t b1 = b0 + kDfChunk < end ? b0 + kDfChunk : end;
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) {
+    const int32_t id = sidx[i];
+    if (id < 0) continue;
+    uint32_t h = static_cast<uint32_t>(df_hash(id)) & (kDfSlots - 1);
+    while (true) {  // terminates: at most kDfChunk distinct ids in kDfSlots slots
+      const int32_t cur = lk[h];
+      if (cur == id) break;
+      if (cur == -1) {
+        const int32_t prev = atomicCAS(&lk[h], -1, id);
+        if (prev == -1 || prev == id) break;
+      }
+      h = (h + 1) & (kDfSlots - 1);
+    }
+    atomicAdd(&lc[h], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDfSlots; i += 256)
+    if (lk[i] != -1) df_add(keys, cnt, cap, lk[i], lc[i], distinct);
 }
 
 int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
@@ -198,7 +227,7 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
                      e->sp_val.p, e->row_slice.p);
   const int64_t region = used - e->sp_used;
   if (region > 0 && account)
-    hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((region + 255) / 256)),
+    hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((region + kDfChunk - 1) / kDfChunk)),
                        dim3(256), 0, e->stream, e->sp_idx.p, e->sp_used, used, e->df_keys.p,
                        e->df_cnt.p, e->df_cap, e->df_distinct);
   VR_HIP(hipGetLastError());
