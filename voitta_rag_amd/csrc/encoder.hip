@@ -1500,10 +1500,11 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   return 0;
 }
 
-// Tokens per forward pass. Large enough that the 768-wide GEMMs still launch several full rounds of
-// 256x256 tiles (131072 tokens x 768 columns = 1536 tiles on 256 CUs); activations for it are
-// ~45 KB per token (5.9 GB). VR_CHUNK_TOKENS overrides it for experiments.
-static const int64_t kMaxChunkTokens = getenv("VR_CHUNK_TOKENS") ? atoll(getenv("VR_CHUNK_TOKENS")) : 131072;
+// Tokens per forward pass. Large enough that the 768-wide GEMMs launch many full rounds of 256x256
+// tiles (262144 tokens x 768 columns = 3072 tiles on 256 CUs: the partly filled last round is then
+// a few per cent of the launch); activations for it are ~45 KB per token (11.8 GB of the 288).
+// VR_CHUNK_TOKENS overrides it for experiments.
+static const int64_t kMaxChunkTokens = getenv("VR_CHUNK_TOKENS") ? atoll(getenv("VR_CHUNK_TOKENS")) : 262144;
 
 int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int n_seq, int mem,
                    float* out, int out_mem) {
