@@ -760,6 +760,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
           glds16(src + nk0, nd + (piece >> 2) * 256 * 64 + (piece & 3) * 64 * 64);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the load where it was written, between the MFMA rows
+        // (measured: dropping this barrier, or s_setprio(1) around the MFMA rows, changes nothing: +-0.5 %)
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K-tile kt+1 have landed
