@@ -47,7 +47,8 @@ struct Encoder {
   // workspace for up to ws_tokens packed tokens
   int64_t ws_tokens = 0;
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
-  float* xs = nullptr;  // f16x3 mode: the hidden state split as (hi, lo) f16 — T*H halfs each
+  float* xs = nullptr;  // f16x3 / f16 mode: the hidden state as GEMM input ((hi, lo) or plain f16 rows)
+  float* lnstat = nullptr;  // f16 mode: two arrays of per-row (mean, 1/sigma), see forward_chunk
   DevArray<int32_t> ids, cu;
   DevArray<float> out;
 };
@@ -106,13 +107,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // Callers pass hi = base and lo = base + 8; split_at() turns a column into the offset inside a row.
 __host__ __device__ __forceinline__ int split_at(int k) { return ((k >> 3) << 4) + (k & 7); }
 
+// one element of a LayerNorm output, exactly as row_layernorm computes it (same operations, same order)
+__device__ __forceinline__ float ln_apply(float v, float mean, float inv, float g, float b) {
+  return (v - mean) * inv * g + b;
+}
+
 // LayerNorm of one row held as float2 pairs per lane (biased variance, eps inside the sqrt).
 // out_hi/out_lo (optional): the same row split for the f16x3 GEMMs.
 __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs, int H,
                                               const float* __restrict__ g,
                                               const float* __restrict__ b, float eps, int lane,
                                               float* __restrict__ out, half_t* __restrict__ out_hi = nullptr,
-                                              half_t* __restrict__ out_lo = nullptr) {
+                                              half_t* __restrict__ out_lo = nullptr,
+                                              float2* __restrict__ stat = nullptr) {
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < kMaxPairs; ++i)
@@ -127,6 +134,9 @@ __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs,
     }
   const float var = wave_sum(q) / static_cast<float>(H);
   const float inv = 1.0f / sqrtf(var + eps);
+  // stat (optional): the row's (mean, 1/sigma) — whoever holds the pre-LN row can then re-derive the
+  // f32 output with ln_apply() instead of reading it back (see forward_chunk, f16 mode)
+  if (stat && lane == 0) *stat = make_float2(mean, inv);
 #pragma unroll
   for (int i = 0; i < kMaxPairs; ++i)
     if (i < pairs) {
@@ -136,7 +146,7 @@ __device__ __forceinline__ void row_layernorm(float2 (&v)[kMaxPairs], int pairs,
       float2 o;
       o.x = (v[i].x - mean) * inv * gg.x + bb.x;
       o.y = (v[i].y - mean) * inv * gg.y + bb.y;
-      *reinterpret_cast<float2*>(out + e) = o;
+      if (out) *reinterpret_cast<float2*>(out + e) = o;
       if (out_hi) {
         half2_t h, l;
         split_f16(o.x, h.x, l.x);
@@ -161,7 +171,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps,
                                                        float* __restrict__ x, half_t* __restrict__ x_hi,
-                                                       half_t* __restrict__ x_lo) {
+                                                       half_t* __restrict__ x_lo, float* __restrict__ pre,
+                                                       float2* __restrict__ stat) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -186,16 +197,18 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       float2 tt = *reinterpret_cast<const float2*>(type + e);
       v[i].x = w.x + pp.x + tt.x;
       v[i].y = w.y + pp.y + tt.y;
+      if (pre) *reinterpret_cast<float2*>(pre + static_cast<int64_t>(t) * H + e) = v[i];  // the pre-LN row
     }
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, x + o, x_hi ? x_hi + (x_lo ? 2 : 1) * o : nullptr, x_lo ? x_lo + 2 * o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, x ? x + o : nullptr, x_hi ? x_hi + (x_lo ? 2 : 1) * o : nullptr,
+                x_lo ? x_lo + 2 * o : nullptr, stat ? stat + t : nullptr);
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int T, int H,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, float eps,
                                                         float* __restrict__ out, half_t* __restrict__ out_hi,
-                                                        half_t* __restrict__ out_lo) {
+                                                        half_t* __restrict__ out_lo, float2* __restrict__ stat) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -205,7 +218,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < kMaxPairs; ++i)
     if (i < pairs) v[i] = *reinterpret_cast<const float2*>(in + static_cast<int64_t>(t) * H + (i * 64 + lane) * 2);
   const int64_t o = static_cast<int64_t>(t) * H;
-  row_layernorm(v, pairs, H, g, b, eps, lane, out + o, out_hi ? out_hi + (out_lo ? 2 : 1) * o : nullptr, out_lo ? out_lo + 2 * o : nullptr);
+  row_layernorm(v, pairs, H, g, b, eps, lane, out ? out + o : nullptr, out_hi ? out_hi + (out_lo ? 2 : 1) * o : nullptr,
+                out_lo ? out_lo + 2 * o : nullptr, stat ? stat + t : nullptr);
 }
 
 // one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
@@ -261,12 +275,32 @@ __global__ __launch_bounds__(256) void gather_first_rows_kernel(const float4* __
   for (int c = lane; c < row_f4; c += 64) dst[static_cast<int64_t>(i) * row_f4 + c] = src[static_cast<int64_t>(t) * row_f4 + c];
 }
 
+// dst[i] = LayerNorm output of the first token of sequence seq0 + i, re-derived from the pre-LN rows
+// and their (mean, 1/sigma) — the f32 hidden state is not stored in f16 mode. One wave per row.
+__global__ __launch_bounds__(256) void gather_first_rows_ln_kernel(const float* __restrict__ pre,
+                                                                   const float2* __restrict__ stat,
+                                                                   const float* __restrict__ g,
+                                                                   const float* __restrict__ b,
+                                                                   const int32_t* __restrict__ cu, int seq0,
+                                                                   int tok_base, int n, int T, int H,
+                                                                   float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int t = min(cu[seq0 + i] - tok_base, T - 1);
+  const float2 st = stat[t];
+  for (int c = lane; c < H; c += 64)
+    dst[static_cast<int64_t>(i) * H + c] = ln_apply(pre[static_cast<int64_t>(t) * H + c], st.x, st.y, g[c], b[c]);
+}
+
 // ---- GEMM: C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU | + R) ---------------------------------------
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;  // padded LDS row (floats); rows stay 16-byte aligned
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3 };  // F16: plain f16 output (256-tile kernel only)
+// F16: plain f16 output; RESIDUAL_LN: the residual is LayerNorm(R) re-derived from the pre-LN rows R and
+// their (mean, 1/sigma) — both in the 256-tile kernel only
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3, EPI_BIAS_RESIDUAL_LN = 4 };
 
 // Linear tile id -> (row panel, column panel), row panels taken kGroupM at a time with the column
 // index slow inside a group. The ~32 blocks an XCD runs together then cover ~8 row panels x ~4
@@ -632,7 +666,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Al, const half_t* __restrict__ Wh,
     const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
     float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
-    float unscale, long long* __restrict__ stamps) {
+    float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b, long long* __restrict__ stamps) {
   __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object of the kernel (a second one makes hipcc
                                            // drain the in-flight loads before every fragment read)
   const int tiles_n = (N + GBN - 1) / GBN;  // N may end inside the last column tile (rows clamped, stores guarded)
@@ -779,21 +814,32 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   const int gcol = bn + wn * 64 + c4;
   const bool col_ok = gcol < N;  // N % 4 == 0: a lane's four columns are in or out together
   const float4 b4 = *reinterpret_cast<const float4*>(bias + (col_ok ? gcol : 0));
+  constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN;
+  float4 lg4 = make_float4(0.f, 0.f, 0.f, 0.f), lb4 = lg4;  // LayerNorm weight / bias of this lane's columns
+  if (EPI == EPI_BIAS_RESIDUAL_LN) {
+    lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
+    lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
+  }
   float4 r4[2][8];  // residual rows of the current tile and of the next one (requested a tile ahead)
-  if (EPI == EPI_BIAS_RESIDUAL) {
+  float2 st4[2][8];  // ... and their (mean, 1/sigma) when the residual is a LayerNorm output
+  if (kResidual) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
-      r4[0][it] = *reinterpret_cast<const float4*>(
-          R + static_cast<int64_t>(min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1)) * N + (col_ok ? gcol : 0));
+    for (int it = 0; it < 8; ++it) {
+      const int64_t rr = min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1);
+      r4[0][it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
+      if (EPI == EPI_BIAS_RESIDUAL_LN) st4[0][it] = ln_stat[rr];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row0 = bm + wm * 128 + i * 32 + (lane >> 4);  // + 4 * it
-    if (EPI == EPI_BIAS_RESIDUAL && i + 1 < 4) {
+    if (kResidual && i + 1 < 4) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
-        r4[(i + 1) & 1][it] = *reinterpret_cast<const float4*>(
-            R + static_cast<int64_t>(min(row0 + 32 + 4 * it, M - 1)) * N + (col_ok ? gcol : 0));
+      for (int it = 0; it < 8; ++it) {
+        const int64_t rr = min(row0 + 32 + 4 * it, M - 1);
+        r4[(i + 1) & 1][it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
+        if (EPI == EPI_BIAS_RESIDUAL_LN) st4[(i + 1) & 1][it] = ln_stat[rr];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -840,10 +886,17 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
           v.z += r4[i & 1][it].z;
           v.w += r4[i & 1][it].w;
         }
+        if (EPI == EPI_BIAS_RESIDUAL_LN) {  // residual = LayerNorm(R row), exactly as the LN kernel would have stored it
+          const float2 st = st4[i & 1][it];
+          v.x += ln_apply(r4[i & 1][it].x, st.x, st.y, lg4.x, lb4.x);
+          v.y += ln_apply(r4[i & 1][it].y, st.x, st.y, lg4.y, lb4.y);
+          v.z += ln_apply(r4[i & 1][it].z, st.x, st.y, lg4.z, lb4.z);
+          v.w += ln_apply(r4[i & 1][it].w, st.x, st.y, lg4.w, lb4.w);
+        }
         *reinterpret_cast<float4*>(C + o) = v;
       }
     };
-    if constexpr (EPI == EPI_BIAS_RESIDUAL) {  // r4[] needs compile-time indices
+    if constexpr (kResidual) {  // r4[] needs compile-time indices
 #pragma unroll
       for (int it = 0; it < 8; ++it) emit(it);
     } else {  // four rows at a time: deeper unrolling only lengthened these two epilogues
@@ -896,32 +949,27 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int
 template <int PASSES>
 static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Al, const half_t* Wh,
                        const half_t* Wl, const float* bias, const float* R, float* C, half_t* Ch, half_t* Cl, int M,
-                       int N, int K, float unscale, long long* stamps) {
+                       int N, int K, float unscale, const float2* ln_stat, const float* ln_g, const float* ln_b,
+                       long long* stamps) {
+#define VR_LAUNCH_256(E)                                                                                         \
+  hipLaunchKernelGGL((gemm_f16x3_256_kernel<E, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R, C, \
+                     Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps)
   switch (epi) {
-    case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R,
-                         C, Ch, Cl, M, N, K, unscale, stamps);
-      break;
-    case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_GELU, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
-                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
-      break;
-    case EPI_BIAS_F16:
-      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_F16, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
-                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
-      break;
-    default:
-      hipLaunchKernelGGL((gemm_f16x3_256_kernel<EPI_BIAS_RESIDUAL, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl,
-                         bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
-      break;
+    case EPI_BIAS: VR_LAUNCH_256(EPI_BIAS); break;
+    case EPI_BIAS_GELU: VR_LAUNCH_256(EPI_BIAS_GELU); break;
+    case EPI_BIAS_F16: VR_LAUNCH_256(EPI_BIAS_F16); break;
+    case EPI_BIAS_RESIDUAL_LN: VR_LAUNCH_256(EPI_BIAS_RESIDUAL_LN); break;
+    default: VR_LAUNCH_256(EPI_BIAS_RESIDUAL); break;
   }
+#undef VR_LAUNCH_256
 }
 
 // passes = 3: operands are interleaved (hi, lo) rows (Al = Ah + 8, Wl = Wh + 8); passes = 1: plain f16
 // rows, Al / Wl / Cl unused.
 static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half_t* Al, const half_t* Wh,
                              const half_t* Wl, float unscale, const float* bias, const float* R, float* C,
-                             half_t* Ch, half_t* Cl, int M, int N, int K, int passes = 3) {
+                             half_t* Ch, half_t* Cl, int M, int N, int K, int passes = 3,
+                             const float2* ln_stat = nullptr, const float* ln_g = nullptr, const float* ln_b = nullptr) {
   VR_CHECK(N % 4 == 0 && K % HBK_ == 0, "GEMM shape N=%d K=%d: N must be a multiple of 4, K of %d", N, K, HBK_);
   if (M <= 0) return 0;
   hipStream_t s = e->stream;
@@ -934,9 +982,9 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
     long long* stamps = nullptr;
     if (want_stamps && stamp_prints < 12) VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), sizeof(long long) * 4 * grid256));
     if (passes == 1)
-      launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+      launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps);
     else
-      launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, stamps);
+      launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps);
     prof_end(e);
     if (stamps) {
       std::vector<long long> h(static_cast<size_t>(4) * grid256);
@@ -1372,6 +1420,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->tmp));
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * I, 0, &enc->ffn));
   if (enc->d.precision != VR_PRECISION_F32) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->xs));
+  if (enc->d.precision == VR_PRECISION_F16) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * 4, 0, &enc->lnstat));
   enc->ws_tokens = tokens;
   return 0;
 }
@@ -1396,9 +1445,26 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   half_t* cl = split && !plain ? ch + 8 : nullptr;
   half_t* fh = split ? reinterpret_cast<half_t*>(enc->ffn) : nullptr;
   half_t* fl = split && !plain ? fh + 8 : nullptr;
+  // f16 mode does not store the f32 hidden state at all. A LayerNorm writes its f16 output (the next
+  // GEMM's input) and the row's (mean, 1/sigma); the only other reader of the hidden state is the
+  // residual add of the next projection's epilogue, which already reads 4 bytes per element — it
+  // reads the PRE-LN row instead and re-derives the LayerNorm output (ln_apply: same operations,
+  // same bits). That takes 4 of the 10 bytes per element out of every LayerNorm pass. The pre-LN
+  // rows alternate between enc->tmp and enc->x; `cur` describes the current hidden state.
+  struct Hidden {
+    const float* pre;
+    const float2* stat;
+    const float* g;
+    const float* b;
+  };
+  float2* stat_a = reinterpret_cast<float2*>(enc->lnstat);
+  float2* stat_b = plain ? stat_a + T : nullptr;
+  Hidden cur{enc->x, stat_b, enc->lng, enc->lnb};
+  const float* final_x = enc->x;  // the f32 rows pooling reads
+  const bool lnfuse = plain && !enc->layers.empty();  // (a model without layers pools the embedding LayerNorm's output)
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
-                     enc->x, xh, xl);
+                     lnfuse ? nullptr : enc->x, xh, xl, lnfuse ? enc->x : nullptr, lnfuse ? stat_b : nullptr);
   const int qblocks = (max_len + 63) / 64;
   const float scale = 1.0f / sqrtf(static_cast<float>(dh));
   // CLS pooling reads one row per sequence, so everything after the LAST layer's attention is needed
@@ -1448,8 +1514,12 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       const unsigned cblocks = gblocks;
       hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->ctx),
                          cu_dev, seq0, tok_base, n_seq, T, plain ? H / 8 : H / 4, reinterpret_cast<float4*>(ctxc));
-      hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->x),
-                         cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(xc));
+      if (plain)
+        hipLaunchKernelGGL(gather_first_rows_ln_kernel, dim3(gblocks), dim3(256), 0, s, cur.pre, cur.stat, cur.g, cur.b,
+                           cu_dev, seq0, tok_base, n_seq, T, H, xc);
+      else
+        hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->x),
+                           cu_dev, seq0, tok_base, n_seq, T, H / 4, reinterpret_cast<float4*>(xc));
       half_t* xch = reinterpret_cast<half_t*>(xsc);
       half_t* cch = reinterpret_cast<half_t*>(ctxc);
       half_t* fch = reinterpret_cast<half_t*>(ffnc);
@@ -1459,7 +1529,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       else
         VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ctxc, w.wo, w.bo, xc, tmpc, n_seq, H, H));
       hipLaunchKernelGGL(layernorm_kernel, dim3(cblocks), dim3(256), 0, s, tmpc, n_seq, H, w.ln1g, w.ln1b, d.eps, xc,
-                         split ? xch : nullptr, split && !plain ? xch + 8 : nullptr);
+                         split ? xch : nullptr, split && !plain ? xch + 8 : nullptr, static_cast<float2*>(nullptr));
       if (split) {
         VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xch, plain ? nullptr : xch + 8, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr, nullptr,
                                  fch, plain ? nullptr : fch + 8, n_seq, I, H, passes));
@@ -1470,11 +1540,34 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
         VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, ffnc, w.w2, w.b2, xc, tmpc, n_seq, H, I));
       }
       hipLaunchKernelGGL(layernorm_kernel, dim3(cblocks), dim3(256), 0, s, tmpc, n_seq, H, w.ln2g, w.ln2b, d.eps, xc,
-                         static_cast<half_t*>(nullptr), static_cast<half_t*>(nullptr));
+                         static_cast<half_t*>(nullptr), static_cast<half_t*>(nullptr), static_cast<float2*>(nullptr));
       hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(256), 0, s, xc, cu_dev, seq0, tok_base, H,
                          d.pooling, d.normalize, 1, out_dev);
       VR_HIP(hipGetLastError());
       return 0;
+    }
+    if (plain) {
+      // hidden state = LN(cur.pre): pre-LN rows alternate between the two buffers
+      float* t1 = cur.pre == enc->x ? enc->tmp : enc->x;
+      float2* s1 = cur.stat == stat_b ? stat_a : stat_b;
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre, t1,
+                               nullptr, nullptr, T, H, H, 1, cur.stat, cur.g, cur.b));
+      hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
+                         static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s1);
+      const Hidden mid{t1, s1, w.ln1g, w.ln1b};
+      float* t2 = const_cast<float*>(cur.pre);  // its last reader (the epilogue above) is done
+      float2* s2 = const_cast<float2*>(cur.stat);
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, nullptr, w.s_1.hi, nullptr, w.s_1.unscale, w.b1, nullptr, nullptr, fh,
+                               nullptr, T, I, H, 1));
+      VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre, t2,
+                               nullptr, nullptr, T, H, I, 1, mid.stat, mid.g, mid.b));
+      // the last LayerNorm of the network also stores its f32 rows (into the free buffer): pooling reads them
+      const bool last = li + 1 == enc->layers.size();
+      hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
+                         last ? t1 : static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s2);
+      cur = Hidden{t2, s2, w.ln2g, w.ln2b};
+      if (last) final_x = t1;
+      continue;
     }
     if (split)
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL, ch, cl, w.s_o.hi, w.s_o.lo, w.s_o.unscale, w.bo, enc->x,
@@ -1482,7 +1575,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     else
       VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ctx, w.wo, w.bo, enc->x, enc->tmp, T, H, H));
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln1g, w.ln1b,
-                       d.eps, enc->x, xh, xl);
+                       d.eps, enc->x, xh, xl, static_cast<float2*>(nullptr));
     if (split) {
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, xl, w.s_1.hi, w.s_1.lo, w.s_1.unscale, w.b1, nullptr,
                                nullptr, fh, fl, T, I, H, passes));
@@ -1493,9 +1586,9 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       VR_TRY(launch_gemm(e, EPI_BIAS_RESIDUAL, enc->ffn, w.w2, w.b2, enc->x, enc->tmp, T, H, I));
     }
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, enc->tmp, T, H, w.ln2g, w.ln2b,
-                       d.eps, enc->x, xh, xl);
+                       d.eps, enc->x, xh, xl, static_cast<float2*>(nullptr));
   }
-  hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(seq1 - seq0)), dim3(256), 0, s, enc->x, cu_dev,
+  hipLaunchKernelGGL(pool_kernel, dim3(static_cast<unsigned>(seq1 - seq0)), dim3(256), 0, s, final_x, cu_dev,
                      seq0, tok_base, H, d.pooling, d.normalize, 0, out_dev);
   VR_HIP(hipGetLastError());
   return 0;
