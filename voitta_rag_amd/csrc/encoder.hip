@@ -222,6 +222,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 out_lo ? out_lo + 2 * o : nullptr, stat ? stat + t : nullptr);
 }
 
+// f16-mode LayerNorm for H % 256 == 0: the row as float4 per lane (16-byte loads, 8-byte f16 stores —
+// the generic kernel's 8-/4-byte accesses reached 4.6 TB/s on this 6-bytes-per-element pass). Writes the
+// f16 row, the row's (mean, 1/sigma), and the f32 row only when `out` is given.
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ in, int T, int H,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            float eps, float* __restrict__ out,
+                                                            half_t* __restrict__ out_h, float2* __restrict__ stat) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int quads = H / 256;  // <= 4
+  const int64_t o = static_cast<int64_t>(t) * H;
+  float4 v[4];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < quads) {
+      v[i] = *reinterpret_cast<const float4*>(in + o + (i * 64 + lane) * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  const float mean = wave_sum(s) / static_cast<float>(H);
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < quads) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float var = wave_sum(q) / static_cast<float>(H);
+  const float inv = 1.0f / sqrtf(var + eps);
+  if (stat && lane == 0) stat[t] = make_float2(mean, inv);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < quads) {
+      const int e = (i * 64 + lane) * 4;
+      const float4 gg = *reinterpret_cast<const float4*>(g + e);
+      const float4 bb = *reinterpret_cast<const float4*>(b + e);
+      float4 r;
+      r.x = ln_apply(v[i].x, mean, inv, gg.x, bb.x);
+      r.y = ln_apply(v[i].y, mean, inv, gg.y, bb.y);
+      r.z = ln_apply(v[i].z, mean, inv, gg.z, bb.z);
+      r.w = ln_apply(v[i].w, mean, inv, gg.w, bb.w);
+      if (out) *reinterpret_cast<float4*>(out + o + e) = r;
+      half_t h[4], l[4];
+      split_f16(r.x, h[0], l[0]);
+      split_f16(r.y, h[1], l[1]);
+      split_f16(r.z, h[2], l[2]);
+      split_f16(r.w, h[3], l[3]);
+      *reinterpret_cast<uint2*>(out_h + o + e) = *reinterpret_cast<const uint2*>(h);
+    }
+}
+
 // one block per sequence: mean (sum / max(count, 1e-9)) or CLS pooling, then x / max(|x|, 1e-12)
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
                                                    const int32_t* __restrict__ cu, int seq0,
@@ -1169,8 +1221,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // (g, tile parity, r): slot 8g + 4b + r = key 32u + 16b + 4g + r. V is staged TRANSPOSED in that
 // order (sVt[d][slot]), so its A fragments are plain 16-byte reads. 16 MFMAs of 16 cycles per 64
 // keys against 128 of 32 cycles in the f32 kernel: the kernel is bound by the softmax's VALU work.
-template <int DH>
-__global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* __restrict__ qkv,
+// NW waves = 16 * NW queries per block.
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_f16_kernel(const half_t* __restrict__ qkv,
                                                             const int32_t* __restrict__ cu, int seq0,
                                                             int tok_base, int H, int qblocks, float scale,
                                                             half_t* __restrict__ ctx_h) {
@@ -1185,13 +1238,13 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* __rest
   const int head = blockIdx.y;
   const int t0 = cu[seq] - tok_base;
   const int len = cu[seq + 1] - cu[seq];
-  if (qb * 64 >= len) return;
+  if (qb * (NW * 16) >= len) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
-  const int q_tok = qb * 64 + wave * 16 + qi;
+  const int q_tok = qb * (NW * 16) + wave * 16 + qi;
   const bool q_valid = q_tok < len;
   const int64_t row3 = 3 * static_cast<int64_t>(H);
 
@@ -1210,7 +1263,7 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* __rest
 
   for (int kt = 0; kt < len; kt += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * (DH / 8); idx += 256) {
+    for (int idx = tid; idx < 64 * (DH / 8); idx += NW * 64) {
       const int key = idx / (DH / 8), c8 = idx % (DH / 8);
       uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
       if (kt + key < len) {
@@ -1496,11 +1549,11 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     const int qb = tail ? 1 : qblocks;  // tail: only the query block that holds token 0 of every sequence
     dim3 agrid(static_cast<unsigned>(n_seq * qb), static_cast<unsigned>(nh));
     prof_begin(e, VR_PROF_ATTENTION, tail ? attn_flop / qblocks : attn_flop);
-    if (plain && dh == 64)
-      hipLaunchKernelGGL((attention_f16_kernel<64>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
+    if (plain && dh == 64)  // (8 waves = 128 queries per block stage K/V once per 128-token sequence, and measured 30 % slower)
+      hipLaunchKernelGGL((attention_f16_kernel<64, 4>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
                          cu_dev, seq0, tok_base, H, qb, scale, ch);
     else if (plain)
-      hipLaunchKernelGGL((attention_f16_kernel<32>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
+      hipLaunchKernelGGL((attention_f16_kernel<32, 4>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
                          cu_dev, seq0, tok_base, H, qb, scale, ch);
     else if (dh == 64)
       hipLaunchKernelGGL((attention_kernel<64>), agrid, dim3(256), 0, s, enc->qkv, cu_dev, seq0, tok_base, H,
@@ -1552,8 +1605,12 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       float2* s1 = cur.stat == stat_b ? stat_a : stat_b;
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre, t1,
                                nullptr, nullptr, T, H, H, 1, cur.stat, cur.g, cur.b));
-      hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
-                         static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s1);
+      if (H % 256 == 0)
+        hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
+                           static_cast<float*>(nullptr), xh, s1);
+      else
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
+                           static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s1);
       const Hidden mid{t1, s1, w.ln1g, w.ln1b};
       float* t2 = const_cast<float*>(cur.pre);  // its last reader (the epilogue above) is done
       float2* s2 = const_cast<float2*>(cur.stat);
@@ -1563,8 +1620,12 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
                                nullptr, nullptr, T, H, I, 1, mid.stat, mid.g, mid.b));
       // the last LayerNorm of the network also stores its f32 rows (into the free buffer): pooling reads them
       const bool last = li + 1 == enc->layers.size();
-      hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
-                         last ? t1 : static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s2);
+      if (H % 256 == 0)
+        hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
+                           last ? t1 : static_cast<float*>(nullptr), xh, s2);
+      else
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
+                           last ? t1 : static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s2);
       cur = Hidden{t2, s2, w.ln2g, w.ln2b};
       if (last) final_x = t1;
       continue;
