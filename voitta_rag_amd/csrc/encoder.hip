@@ -99,6 +99,24 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x >= 0.0f ? x * fmaf(-0.5f, q, 1.0f) : 0.5f * x * q;
 }
 
+// two elements at a time on the packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32): same operations in the
+// same order as gelu_fast, so the same bits
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 a = (-1.4426950408889634f * z) * z;
+  const f32x2 q = (p * t) * f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const f32x2 pos = x * __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, q, f32x2{1.0f, 1.0f});
+  const f32x2 neg = (0.5f * x) * q;
+  return f32x2{x.x >= 0.0f ? pos.x : neg.x, x.y >= 0.0f ? pos.y : neg.y};
+}
+
 // Split (hi, lo) matrices live in ONE interleaved array: row r of a [rows][K] matrix is 2K halfs,
 // element k's hi at  r*2K + (k/8)*16 + k%8  and its lo 8 halfs further. A 128-byte line then holds
 // 32 consecutive k of BOTH halves of one row — exactly what a 32-deep GEMM K-tile needs of that row,
@@ -911,13 +929,11 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
       v.w = v.w * unscale + b4.w;
       const int64_t o = static_cast<int64_t>(grow) * N + gcol;
       if (EPI == EPI_BIAS_GELU) {
-        float g[4] = {v.x, v.y, v.z, v.w};
+        const f32x2 g01 = gelu_fast2(f32x2{v.x, v.y}), g23 = gelu_fast2(f32x2{v.z, v.w});
+        float g[4] = {g01.x, g01.y, g23.x, g23.y};
         half_t h[4], l[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          g[c] = gelu_fast(g[c]);
-          split_f16(g[c], h[c], l[c]);
-        }
+        for (int c = 0; c < 4; ++c) split_f16(g[c], h[c], l[c]);
         if (PASSES == 3) {
           const int64_t so = static_cast<int64_t>(grow) * (2 * N) + split_at(gcol);
           *reinterpret_cast<uint2*>(Ch + so) = *reinterpret_cast<const uint2*>(h);
