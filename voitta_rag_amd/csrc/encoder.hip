@@ -737,26 +737,31 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     const half_t* __restrict__ Wl, const float* __restrict__ bias, const float* __restrict__ R,
     float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, int K,
     float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
-    const float* __restrict__ ln_b, long long* __restrict__ stamps) {
+    const float* __restrict__ ln_b) {
   __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object of the kernel (a second one makes hipcc
                                            // drain the in-flight loads before every fragment read)
+  // Persistent blocks: the grid is one block per CU and every block walks tiles g, g + G, g + 2G, ...
+  // Inside a wave of G tiles the blocks that share an XCD (blockIdx % 8) take consecutive tiles, and
+  // consecutive tiles are grouped kGroupM256 row panels at a time with the column index slow, so the
+  // A panels and W columns an XCD re-reads stay in its L2.
   const int tiles_n = (N + GBN - 1) / GBN;  // N may end inside the last column tile (rows clamped, stores guarded)
   const int tiles_m = (M + GBM - 1) / GBM;
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-  int tm, tn;
-  {
+  const int total = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int local = (G % 8 == 0) ? (static_cast<int>(blockIdx.x) % 8) * (G / 8) + static_cast<int>(blockIdx.x) / 8
+                                 : static_cast<int>(blockIdx.x);
+  auto coords = [&](int t, int& bm_, int& bn_) {
     const int per_group = kGroupM256 * tiles_n;
-    const int group = swz / per_group;
-    const int within = swz - group * per_group;
+    const int group = t / per_group;
+    const int within = t - group * per_group;
     const int gm = min(kGroupM256, tiles_m - group * kGroupM256);
-    tm = group * kGroupM256 + within % gm;
-    tn = within / gm;
-  }
-  const int bm = tm * GBM;
-  const int bn = tn * GBN;
+    bm_ = (group * kGroupM256 + within % gm) * GBM;
+    bn_ = (within / gm) * GBN;
+  };
+  int tile = local;
+  if (tile >= total) return;  // block-uniform
+  int bm, bn;
+  coords(tile, bm, bn);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,14 +774,18 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
   const int r0 = wave * 8 + srow;  // + 64 j
   const int64_t K2 = (PASSES == 3 ? 2 : 1) * static_cast<int64_t>(K);  // halfs per operand row
-  const half_t* g_a0 = Ah + static_cast<int64_t>(min(bm + r0, M - 1)) * K2 + schunk;
-  const half_t* g_a1 = Ah + static_cast<int64_t>(min(bm + r0 + 64, M - 1)) * K2 + schunk;
-  const half_t* g_a2 = Ah + static_cast<int64_t>(min(bm + r0 + 128, M - 1)) * K2 + schunk;
-  const half_t* g_a3 = Ah + static_cast<int64_t>(min(bm + r0 + 192, M - 1)) * K2 + schunk;
-  const half_t* g_w0 = Wh + static_cast<int64_t>(min(bn + r0, N - 1)) * K2 + schunk;
-  const half_t* g_w1 = Wh + static_cast<int64_t>(min(bn + r0 + 64, N - 1)) * K2 + schunk;
-  const half_t* g_w2 = Wh + static_cast<int64_t>(min(bn + r0 + 128, N - 1)) * K2 + schunk;
-  const half_t* g_w3 = Wh + static_cast<int64_t>(min(bn + r0 + 192, N - 1)) * K2 + schunk;
+  const half_t *g_a0, *g_a1, *g_a2, *g_a3, *g_w0, *g_w1, *g_w2, *g_w3;
+  auto set_ptrs = [&](int bm_, int bn_) {
+    g_a0 = Ah + static_cast<int64_t>(min(bm_ + r0, M - 1)) * K2 + schunk;
+    g_a1 = Ah + static_cast<int64_t>(min(bm_ + r0 + 64, M - 1)) * K2 + schunk;
+    g_a2 = Ah + static_cast<int64_t>(min(bm_ + r0 + 128, M - 1)) * K2 + schunk;
+    g_a3 = Ah + static_cast<int64_t>(min(bm_ + r0 + 192, M - 1)) * K2 + schunk;
+    g_w0 = Wh + static_cast<int64_t>(min(bn_ + r0, N - 1)) * K2 + schunk;
+    g_w1 = Wh + static_cast<int64_t>(min(bn_ + r0 + 64, N - 1)) * K2 + schunk;
+    g_w2 = Wh + static_cast<int64_t>(min(bn_ + r0 + 128, N - 1)) * K2 + schunk;
+    g_w3 = Wh + static_cast<int64_t>(min(bn_ + r0 + 192, N - 1)) * K2 + schunk;
+  };
+  set_ptrs(bm, bn);
   half_t* l_dst = lds + wave * 8 * 64;  // rows of 64 halfs (128 B); the W image starts at 256 * 64
 #define VR_GLDS_STAGE(buf, k0)                                          \
   do {                                                                  \
@@ -792,12 +801,6 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   } while (0)
 
   f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // fragments: lane l supplies row (l & 31), k = 8*(l >> 5) + j of a 16-deep step.
   // PASSES 3: k8-group g = 2*kk + (l >> 5) of the 32-deep tile, hi = chunk 2g, lo = chunk 2g + 1.
@@ -810,21 +813,31 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 
   constexpr int kTileHalfs = 64;               // halfs of one row per K-tile: 32 k x (hi, lo) or 64 k
   const int nk = K / (PASSES == 3 ? 32 : 64);
-  long long t_start = 0, t_loop = 0, t_epi = 0;
-  if (stamps) t_start = __builtin_amdgcn_s_memtime();
+  int par = 0;  // stage buffer holding K-tile 0 of the current tile
   VR_GLDS_STAGE(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (stamps) t_loop = __builtin_amdgcn_s_memtime();
+  while (true) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // the next tile of this block: its first K-tile is loaded during this tile's LAST K-tile, so only the
+  // first tile of a block pays a prologue, and this tile's stores drain under the next main loop
+  const int next = tile + G;
+  const bool has_next = next < total;
+  int nbm = bm, nbn = bn;
+  if (has_next) coords(next, nbm, nbn);
   for (int kt = 0; kt < nk; ++kt) {
-    const half_t* st = lds + (kt & 1) * kStageHalfs;
+    if (kt == nk - 1 && has_next) set_ptrs(nbm, nbn);
+    const half_t* st = lds + ((par + kt) & 1) * kStageHalfs;
     // A direct-to-LDS load holds the issuing wave for ~100+ cycles. Eight of them in a row at the top
     // of the K-tile left the matrix pipe idle for a third of it; instead one load is issued after
     // every row of MFMA tiles, where the partner wave of the SIMD fills the gap.
-    // (the last K-tile re-loads tile 0 into the idle stage instead of branching around every load:
-    //  nothing reads it, and the vmcnt(0) + barrier below retire it before the epilogue reuses LDS)
-    half_t* nd = l_dst + ((kt + 1) & 1) * kStageHalfs;
-    const int nk0 = kt + 1 < nk ? (kt + 1) * kTileHalfs : 0;
+    half_t* nd = l_dst + ((par + kt + 1) & 1) * kStageHalfs;
+    const int nk0 = kt + 1 < nk ? (kt + 1) * kTileHalfs : 0;  // K-tile 0 of the next tile (or, at the very end, a harmless re-load)
     constexpr int kSteps = PASSES == 3 ? 2 : 4;  // 16-deep MFMA steps per K-tile
 #pragma unroll
     for (int kk = 0; kk < kSteps; ++kk) {
@@ -871,15 +884,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K-tile kt+1 have landed
     __syncthreads();                                   // ... everybody's have, and K-tile kt is consumed
   }
-#undef VR_GLDS_STAGE
-  if (stamps) t_epi = __builtin_amdgcn_s_memtime();
 
-  // Epilogue through LDS, one 32-row tile of the wave at a time (see gemm_f16x3_kernel): the wave
-  // parks 32x64 accumulators in its own region and reads them back by rows for 16-byte accesses.
+  // Epilogue through LDS, 16 rows of the wave at a time (see gemm_f16x3_kernel): the wave parks 16x64
+  // accumulators in its own region of the stage buffer that does NOT hold the next tile's first K-tile
+  // and reads them back by rows for 16-byte accesses.
   // The residual rows of a tile are requested one tile AHEAD, all eight loads at once: read one by
   // one inside the store loop they cost eight exposed HBM latencies per tile.
   constexpr int SLD = 64 + 4;
-  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SLD);
+  const int sbuf = ((par + nk) & 1) ^ 1;
+  float* stage = reinterpret_cast<float*>(lds) + sbuf * (kStageHalfs / 2) + wave * (16 * SLD);
   const int c4 = (lane & 15) * 4;
   const int gcol = bn + wn * 64 + c4;
   const bool col_ok = gcol < N;  // N % 4 == 0: a lane's four columns are in or out together
@@ -890,32 +903,30 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
     lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
   }
-  float4 r4[2][8];  // residual rows of the current tile and of the next one (requested a tile ahead)
-  float2 st4[2][8];  // ... and their (mean, 1/sigma) when the residual is a LayerNorm output
-  if (kResidual) {
+  // The residual rows of a 16-row piece are requested one piece AHEAD, four loads at once (read one
+  // by one inside the store loop they cost an exposed HBM latency each), with their (mean, 1/sigma)
+  // when the residual is a LayerNorm output.
+  float4 r4[2][4];
+  float2 st4[2][4];
+  auto fetch_residual = [&](int pc, float4 (&r)[4], float2 (&st)[4]) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int64_t rr = min(bm + wm * 128 + (lane >> 4) + 4 * it, M - 1);
-      r4[0][it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
-      if (EPI == EPI_BIAS_RESIDUAL_LN) st4[0][it] = ln_stat[rr];
+    for (int it = 0; it < 4; ++it) {
+      const int64_t rr = min(bm + wm * 128 + 16 * pc + (lane >> 4) + 4 * it, M - 1);
+      r[it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
+      if (EPI == EPI_BIAS_RESIDUAL_LN) st[it] = ln_stat[rr];
     }
-  }
+  };
+  if (kResidual) fetch_residual(0, r4[0], st4[0]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row0 = bm + wm * 128 + i * 32 + (lane >> 4);  // + 4 * it
-    if (kResidual && i + 1 < 4) {
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int64_t rr = min(row0 + 32 + 4 * it, M - 1);
-        r4[(i + 1) & 1][it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
-        if (EPI == EPI_BIAS_RESIDUAL_LN) st4[(i + 1) & 1][it] = ln_stat[rr];
-      }
-    }
+  for (int pc = 0; pc < 8; ++pc) {  // piece pc = rows 16 pc .. 16 pc + 15 of the wave's 128: MFMA tile i, half h
+    const int i = pc >> 1, h = pc & 1;
+    const int row0 = bm + wm * 128 + 16 * pc + (lane >> 4);  // + 4 * it
+    if (kResidual && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+      for (int r = 0; r < 8; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][8 * h + r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     auto emit = [&](int it) {
@@ -949,38 +960,34 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
         *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
       } else {
         if (EPI == EPI_BIAS_RESIDUAL) {
-          v.x += r4[i & 1][it].x;
-          v.y += r4[i & 1][it].y;
-          v.z += r4[i & 1][it].z;
-          v.w += r4[i & 1][it].w;
+          v.x += r4[pc & 1][it].x;
+          v.y += r4[pc & 1][it].y;
+          v.z += r4[pc & 1][it].z;
+          v.w += r4[pc & 1][it].w;
         }
         if (EPI == EPI_BIAS_RESIDUAL_LN) {  // residual = LayerNorm(R row), exactly as the LN kernel would have stored it
-          const float2 st = st4[i & 1][it];
-          v.x += ln_apply(r4[i & 1][it].x, st.x, st.y, lg4.x, lb4.x);
-          v.y += ln_apply(r4[i & 1][it].y, st.x, st.y, lg4.y, lb4.y);
-          v.z += ln_apply(r4[i & 1][it].z, st.x, st.y, lg4.z, lb4.z);
-          v.w += ln_apply(r4[i & 1][it].w, st.x, st.y, lg4.w, lb4.w);
+          const float2 st = st4[pc & 1][it];
+          v.x += ln_apply(r4[pc & 1][it].x, st.x, st.y, lg4.x, lb4.x);
+          v.y += ln_apply(r4[pc & 1][it].y, st.x, st.y, lg4.y, lb4.y);
+          v.z += ln_apply(r4[pc & 1][it].z, st.x, st.y, lg4.z, lb4.z);
+          v.w += ln_apply(r4[pc & 1][it].w, st.x, st.y, lg4.w, lb4.w);
         }
         *reinterpret_cast<float4*>(C + o) = v;
       }
     };
-    if constexpr (kResidual) {  // r4[] needs compile-time indices
 #pragma unroll
-      for (int it = 0; it < 8; ++it) emit(it);
-    } else {  // four rows at a time: deeper unrolling only lengthened these two epilogues
-#pragma unroll 4
-      for (int it = 0; it < 8; ++it) emit(it);
-    }
+    for (int it = 0; it < 4; ++it) emit(it);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();  // the rows are read before the next tile overwrites the region
+    __builtin_amdgcn_wave_barrier();  // the rows are read before the next piece overwrites the region
   }
-  if (stamps && tid == 0) {  // diagnostic build only (VR_GEMM_STAMPS): phase lengths of this block, in shader cycles
-    const long long t_end = __builtin_amdgcn_s_memtime();
-    stamps[blockIdx.x * 4 + 0] = t_loop - t_start;
-    stamps[blockIdx.x * 4 + 1] = t_epi - t_loop;
-    stamps[blockIdx.x * 4 + 2] = t_end - t_epi;
-    stamps[blockIdx.x * 4 + 3] = t_start;
-  }
+  if (!has_next) break;
+  par = (par + nk) & 1;
+  tile = next;
+  bm = nbm;
+  bn = nbn;
+  __syncthreads();  // every wave has left the staging buffer before the next tile's loads land in it
+  }  // tiles
+#undef VR_GLDS_STAGE
 }
 
 // weights: w * scale -> (hi, lo); scale is a power of two chosen from max|w| of the tensor
@@ -1017,11 +1024,10 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int
 template <int PASSES>
 static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Al, const half_t* Wh,
                        const half_t* Wl, const float* bias, const float* R, float* C, half_t* Ch, half_t* Cl, int M,
-                       int N, int K, float unscale, const float2* ln_stat, const float* ln_g, const float* ln_b,
-                       long long* stamps) {
+                       int N, int K, float unscale, const float2* ln_stat, const float* ln_g, const float* ln_b) {
 #define VR_LAUNCH_256(E)                                                                                         \
   hipLaunchKernelGGL((gemm_f16x3_256_kernel<E, PASSES>), dim3(grid), dim3(512), 0, s, Ah, Al, Wh, Wl, bias, R, C, \
-                     Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps)
+                     Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b)
   switch (epi) {
     case EPI_BIAS: VR_LAUNCH_256(EPI_BIAS); break;
     case EPI_BIAS_GELU: VR_LAUNCH_256(EPI_BIAS_GELU); break;
@@ -1044,31 +1050,20 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
   if (passes == 1 || (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128)) {
-    const int grid256 = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
-    static const bool want_stamps = getenv("VR_GEMM_STAMPS") != nullptr;  // diagnostics: phase lengths per block
-    static int stamp_prints = 0;
-    long long* stamps = nullptr;
-    if (want_stamps && stamp_prints < 12) VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), sizeof(long long) * 4 * grid256));
-    if (passes == 1)
-      launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps);
-    else
-      launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b, stamps);
-    prof_end(e);
-    if (stamps) {
-      std::vector<long long> h(static_cast<size_t>(4) * grid256);
-      VR_HIP(hipStreamSynchronize(s));
-      VR_HIP(hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      (void)hipFree(stamps);
-      double p = 0, l = 0, ep = 0;
-      for (int b = 0; b < grid256; ++b) {
-        p += h[4 * b]; l += h[4 * b + 1]; ep += h[4 * b + 2];
-      }
-      const int ktile = passes == 1 ? 64 : 32;
-      fprintf(stderr, "[gemm256 passes=%d epi=%d M=%d N=%d K=%d] blocks %d: prologue %.0f  loop %.0f (%.0f / K-tile)  "
-              "epilogue %.0f cycles\n", passes, epi, M, N, K, grid256, p / grid256, l / grid256, l / grid256 / (K / ktile),
-              ep / grid256);
-      ++stamp_prints;
+    static int n_cu = 0;  // persistent grid: one block per CU (the kernel uses 128 KiB of the CU's LDS)
+    if (n_cu == 0) {
+      hipDeviceProp_t prop;
+      VR_HIP(hipGetDeviceProperties(&prop, e->device));
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
+      if (n_cu == 0) n_cu = prop.multiProcessorCount;
     }
+    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    const int grid256 = std::min(tiles, n_cu);
+    if (passes == 1)
+      launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
+    else
+      launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
+    prof_end(e);
     VR_HIP(hipGetLastError());
     return 0;
   }
