@@ -6,11 +6,9 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum SQ_VMEM_TA_ADDR_FIFO_FULL" \
-           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-           "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
+           ; do  # (a pass with TA_BUSY_avr / TA_*_STALLED_BY_TC_CYCLES_sum aborted rocprofv3 on this pool: left out)
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python $R/scripts/perf_encode.py bge-base-en-v1.5 256 128 2 f16x3 > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/p$i.log; }
+  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python $R/scripts/perf_encode.py bge-base-en-v1.5 256 128 2 f16 > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/p$i.log; }
 done
 python - <<'PY'
 import csv, glob, collections
