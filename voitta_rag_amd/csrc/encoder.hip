@@ -51,6 +51,7 @@ struct Encoder {
   float* lnstat = nullptr;  // f16 mode: two arrays of per-row (mean, 1/sigma), see forward_chunk
   DevArray<int32_t> ids, cu;
   DevArray<float> out;
+  DevArray<float> skinny_ws;  // K-slice partial sums of gemm_f16_skinny_kernel
 };
 
 // ---- elementwise / normalisation ---------------------------------------------------------------
@@ -990,6 +991,117 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #undef VR_GLDS_STAGE
 }
 
+// ---- skinny product for M <= 256 rows (one query, a handful of sequences) ---------------------------
+//
+// With a few rows the 256x256 kernel leaves the chip empty (N / 256 blocks, each walking all of K:
+// 1.7 ms for a 12-token bge-base query). Here the work is cut along N (64 columns per block) AND along
+// K (slices of kSkinnyK), so 50-200 blocks stream disjoint slabs of the weight matrix — the only real
+// traffic — and write f32 partial sums; a second small kernel adds the slices and applies the
+// epilogue. D[n][m] = sum_k W[n][k] A[m][k] on v_mfma_f32_16x16x32_f16: W rows are the MFMA rows, the
+// activation rows (64 per block) its columns; both operands are 16-byte global loads (k contiguous).
+// f16 mode only (plain f16 rows).
+constexpr int kSkinnyM = 64;
+// K slice per block: the largest of these that divides K (192 for 384 / 768 / 1536 / 3072, 256 for 1024 / 4096)
+static int skinny_slice(int K) {
+  for (int c : {192, 256, 128, 64, 32})
+    if (K % c == 0) return c;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void gemm_f16_skinny_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                              float* __restrict__ part, int M, int N, int K,
+                                                              int kslice) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 64 + wave * 16;  // this wave's 16 output columns
+  const int k0 = blockIdx.y * kslice;
+  const int row = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.z * kSkinnyM;  // 64 activation rows per block
+  if (n0 >= N) return;
+  const half_t* wp = W + static_cast<int64_t>(min(n0 + row, N - 1)) * K + k0 + 8 * g;
+  const half_t* ap[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) ap[mb] = A + static_cast<int64_t>(min(m0 + mb * 16 + row, M - 1)) * K + k0 + 8 * g;
+  f32x4 acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mblocks = (min(M - m0, kSkinnyM) + 15) / 16;
+  for (int k = 0; k < kslice; k += 32) {
+    const f16x8 wf = *reinterpret_cast<const f16x8*>(wp + k);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+      if (mb < mblocks) {
+        const f16x8 af = *reinterpret_cast<const f16x8*>(ap[mb] + k);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af, acc[mb], 0, 0, 0);
+      }
+  }
+  // C layout: column (lane & 15) = activation row m, rows 4g + r = output columns n0 + 4g + r
+  float* dst = part + static_cast<int64_t>(blockIdx.y) * M * N;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + mb * 16 + row;
+    if (mb < mblocks && m < M && n0 + 4 * g < N)
+      *reinterpret_cast<float4*>(dst + static_cast<int64_t>(m) * N + n0 + 4 * g) =
+          make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
+  }
+}
+
+// sum of the K slices + the epilogue of the 256-tile kernel (same formulas), one float4 per thread
+template <int EPI>
+__global__ void skinny_epilogue_kernel(const float* __restrict__ part, int slices, int M, int N, float unscale,
+                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                       const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+                                       const float* __restrict__ ln_b, float* __restrict__ C,
+                                       half_t* __restrict__ Ch) {
+  const int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t total4 = static_cast<int64_t>(M) * N / 4;
+  if (i4 >= total4) return;
+  const int64_t o = i4 * 4;
+  const int m = static_cast<int>(o / N), n = static_cast<int>(o % N);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < slices; ++s) {
+    const float4 p = *reinterpret_cast<const float4*>(part + static_cast<int64_t>(s) * M * N + o);
+    v.x += p.x;
+    v.y += p.y;
+    v.z += p.z;
+    v.w += p.w;
+  }
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+  v.x = v.x * unscale + b4.x;
+  v.y = v.y * unscale + b4.y;
+  v.z = v.z * unscale + b4.z;
+  v.w = v.w * unscale + b4.w;
+  if (EPI == EPI_BIAS_GELU) {
+    const f32x2 g01 = gelu_fast2(f32x2{v.x, v.y}), g23 = gelu_fast2(f32x2{v.z, v.w});
+    v = make_float4(g01.x, g01.y, g23.x, g23.y);
+  }
+  if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_F16) {
+    half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
+                   static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
+                   static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
+                   static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
+    *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+    return;
+  }
+  if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN) {
+    const float4 r = *reinterpret_cast<const float4*>(R + o);
+    if (EPI == EPI_BIAS_RESIDUAL_LN) {
+      const float2 st = ln_stat[m];
+      const float4 lg = *reinterpret_cast<const float4*>(ln_g + n), lb = *reinterpret_cast<const float4*>(ln_b + n);
+      v.x += ln_apply(r.x, st.x, st.y, lg.x, lb.x);
+      v.y += ln_apply(r.y, st.x, st.y, lg.y, lb.y);
+      v.z += ln_apply(r.z, st.x, st.y, lg.z, lb.z);
+      v.w += ln_apply(r.w, st.x, st.y, lg.w, lb.w);
+    } else {
+      v.x += r.x;
+      v.y += r.y;
+      v.z += r.z;
+      v.w += r.w;
+    }
+  }
+  *reinterpret_cast<float4*>(C + o) = v;
+}
+
 // weights: w * scale -> (hi, lo); scale is a power of two chosen from max|w| of the tensor
 __global__ void absmax_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
   float m = 0.0f;
@@ -1049,6 +1161,28 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   hipStream_t s = e->stream;
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
+  if (passes == 1 && M <= 4 * kSkinnyM && skinny_slice(K) > 0 && N % 64 == 0) {
+    Encoder* enc = static_cast<Encoder*>(e->encoder);
+    const int kslice = skinny_slice(K), slices = K / kslice;
+    VR_TRY(enc->skinny_ws.grow(static_cast<int64_t>(slices) * M * N, 0, s));
+    hipLaunchKernelGGL(gemm_f16_skinny_kernel, dim3(static_cast<unsigned>(N / 64), static_cast<unsigned>(slices), static_cast<unsigned>((M + kSkinnyM - 1) / kSkinnyM)),
+                       dim3(256), 0, s, Ah, Wh, enc->skinny_ws.p, M, N, K, kslice);
+    const unsigned eb = static_cast<unsigned>((static_cast<int64_t>(M) * N / 4 + 255) / 256);
+#define VR_SKINNY_EPI(E)                                                                                          \
+  hipLaunchKernelGGL((skinny_epilogue_kernel<E>), dim3(eb), dim3(256), 0, s, enc->skinny_ws.p, slices, M, N, unscale, \
+                     bias, R, ln_stat, ln_g, ln_b, C, Ch)
+    switch (epi) {
+      case EPI_BIAS: VR_SKINNY_EPI(EPI_BIAS); break;
+      case EPI_BIAS_GELU: VR_SKINNY_EPI(EPI_BIAS_GELU); break;
+      case EPI_BIAS_F16: VR_SKINNY_EPI(EPI_BIAS_F16); break;
+      case EPI_BIAS_RESIDUAL_LN: VR_SKINNY_EPI(EPI_BIAS_RESIDUAL_LN); break;
+      default: VR_SKINNY_EPI(EPI_BIAS_RESIDUAL); break;
+    }
+#undef VR_SKINNY_EPI
+    prof_end(e);
+    VR_HIP(hipGetLastError());
+    return 0;
+  }
   if (passes == 1 || (N % GBN == 0 && K % GBK == 0 && M >= GBM && force_tile != 128)) {
     static int n_cu = 0;  // persistent grid: one block per CU (the kernel uses 128 KiB of the CU's LDS)
     if (n_cu == 0) {
@@ -1401,6 +1535,7 @@ void encoder_release(vr_engine* e) {
   for (float* p : enc->owned) (void)hipFree(p);
   enc->ids.release();
   enc->cu.release();
+  enc->skinny_ws.release();
   enc->out.release();
   delete enc;
   e->encoder = nullptr;
