@@ -347,16 +347,32 @@ class Engine:
             q = _np(query, np.float32).reshape(self.dim)
             mem, qp = VR_MEM_HOST, C.c_void_p(q.ctypes.data)
         qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
-        rows = np.empty(limit, np.int64)
-        scores = np.empty(limit, np.float64)
-        fd = np.empty(limit, np.int32)
-        c = C.c_int32()
-        fp, keep = self._filter(flt)
-        check(self._lib.vr_search_hybrid(self._h, qp, mem, _ptr(qi, C.c_int32), _ptr(qv, C.c_float), qi.shape[0],
-                                         limit, float(sparse_weight), fusion, fp, _ptr(rows, C.c_int64),
-                                         _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
+        # latency path: output buffers and their addresses are kept per `limit`, and the call goes through a
+        # prototype that takes plain addresses (building five ctypes POINTER objects per query cost ~10 us)
+        slot = self._hybrid_slots.get(limit) if hasattr(self, "_hybrid_slots") else None
+        if slot is None:
+            if not hasattr(self, "_hybrid_slots"):
+                self._hybrid_slots = {}
+                fn = self._lib["vr_search_hybrid"]
+                fn.restype = C.c_int
+                fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double,
+                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                self._hybrid_fn = fn
+            rows, scores, fd = np.empty(limit, np.int64), np.empty(limit, np.float64), np.empty(limit, np.int32)
+            cnt = np.zeros(1, np.int32)
+            slot = (rows, scores, fd, cnt, rows.ctypes.data, scores.ctypes.data, fd.ctypes.data, cnt.ctypes.data)
+            self._hybrid_slots[limit] = slot
+        rows, scores, fd, cnt, rp, sp, fdp, cp = slot
+        if flt is None or flt.is_empty():
+            fptr, keep = None, None
+        else:
+            f, arrays = flt.to_c()
+            fptr, keep = C.addressof(f), (f, arrays)
+        check(self._hybrid_fn(self._h, qp, mem, qi.ctypes.data, qv.ctypes.data, qi.shape[0], limit,
+                              float(sparse_weight), fusion, fptr, rp, sp, fdp, cp))
         del keep
-        return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
+        n = int(cnt[0])
+        return rows[:n].copy(), scores[:n].copy(), fd[:n].copy()
 
 
 def fuse_minmax(d_rows, d_scores, s_rows, s_scores, limit: int, sparse_weight: float, json_scores: bool = True):
