@@ -328,6 +328,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         p50, p99 = float(t[0]), float(t[1])
     dense_only = [engine.search_dense(qs_host[20 + i: 21 + i], 10) for i in range(min(50, args.queries))]
+    # the same query when it arrives as TEXT: WordPiece ids of a short question (12 tokens) are encoded by
+    # the engine first (embed_query's path, embedding.py:76-86), then searched — single GPU only
+    enc_lat = full_lat = None
+    if world == 1:
+        q_ids = np.concatenate([[101], np.random.default_rng(9).integers(1000, 29000, size=10), [102]]).astype(np.int32)
+        q_off = np.asarray([0, q_ids.size], np.int32)
+        e_l, f_l = np.empty(200), np.empty(200)
+        for i in range(220):
+            t1 = time.perf_counter()
+            vec = enc.encode(engine, q_ids, q_off)[0]
+            t2 = time.perf_counter()
+            engine.search_hybrid(vec, q_terms[i % args.queries, : q_nnz[i % args.queries]], ones[: q_nnz[i % args.queries]], 10, 0.1)
+            t3 = time.perf_counter()
+            if i >= 20:
+                e_l[i - 20], f_l[i - 20] = t2 - t1, t3 - t1
+        enc_lat, full_lat = float(np.percentile(e_l, 50) * 1e3), float(np.percentile(f_l, 50) * 1e3)
 
     # ---- recall@10 of the dense scan against a plain torch f32 matmul over the same vectors ------
     recall = None
@@ -381,6 +397,9 @@ def main():
             "p50_query_ms": round(p50, 4),
             "p99_query_ms": round(p99, 4),
             "query_kind": "single-stream hybrid top-10 (dense top-30 + sparse top-30 + fusion), query vector given",
+            "p50_query_encode_ms": None if enc_lat is None else round(enc_lat, 4),
+            "p50_query_from_tokens_ms": None if full_lat is None else round(full_lat, 4),
+            "query_from_tokens_kind": "the same search with the 12-token query embedded by the engine first (vr_encode + vr_search_hybrid)",
             "recall_at_10_dense_vs_torch_matmul": recall,
             # f32: algorithmic FLOP against the f32-MFMA peak. f16x3: every algorithmic multiply-add is
             # three f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOP/s is the dense f16 peak / 3.
