@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "host_parallel.h"
 #include "unicode_tables.inc"
 
 namespace {
@@ -347,13 +348,16 @@ extern "C" {
 int vr_bm25_tokenize(const char* const* texts, const int64_t* lens, int64_t n, int64_t* out_off,
                      int32_t* out_ids, int64_t cap, int64_t* out_needed) {
   VR_CHECK(n >= 0 && out_off && out_needed && (n == 0 || (texts && lens)), "bad arguments");
-  std::vector<int32_t> ids;
+  // texts are independent: all host threads, then the ids in order (a buffer that is too small gets
+  // the leading ids that fit, as before)
+  std::vector<std::vector<int32_t>> per_text(static_cast<size_t>(n));
+  vr::parallel_for(n, 64, [&](int64_t i) {
+    hashed_stems(texts[i], static_cast<size_t>(lens[i]), &per_text[static_cast<size_t>(i)]);
+  });
   int64_t total = 0;
   out_off[0] = 0;
   for (int64_t i = 0; i < n; ++i) {
-    ids.clear();
-    hashed_stems(texts[i], static_cast<size_t>(lens[i]), &ids);
-    for (int32_t v : ids) {
+    for (int32_t v : per_text[static_cast<size_t>(i)]) {
       if (total < cap && out_ids) out_ids[total] = v;
       ++total;
     }

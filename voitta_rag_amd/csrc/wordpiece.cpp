@@ -27,6 +27,7 @@
 
 #include "../../include/voitta_engine.h"
 #include "engine_internal.h"
+#include "host_parallel.h"
 #include "unicode_tables.inc"
 #include "wordpiece_tables.inc"
 
@@ -323,16 +324,22 @@ int vr_wordpiece_encode(const vr_wordpiece* t, const char* const* texts, const i
                         int32_t max_len, int64_t* out_offsets, int32_t* out_ids, int64_t capacity, int64_t* needed) {
   VR_CHECK(t && (n_texts == 0 || (texts && text_lens)) && out_offsets && needed, "bad arguments");
   VR_CHECK(max_len >= 2, "max_len %d cannot hold [CLS] and [SEP]", max_len);
-  std::vector<int32_t> ids;
+  // texts are independent: tokenise them on all host threads, then lay the ids out in order
+  std::vector<std::vector<int32_t>> per_text(static_cast<size_t>(n_texts));
+  vr::parallel_for(n_texts, 64, [&](int64_t i) {
+    encode_one(*t, texts[i], static_cast<size_t>(text_lens[i]), max_len, &per_text[static_cast<size_t>(i)]);
+  });
   int64_t total = 0;
   out_offsets[0] = 0;
   for (int64_t i = 0; i < n_texts; ++i) {
-    encode_one(*t, texts[i], static_cast<size_t>(text_lens[i]), max_len, &ids);
-    if (out_ids && total + static_cast<int64_t>(ids.size()) <= capacity)
-      memcpy(out_ids + total, ids.data(), ids.size() * sizeof(int32_t));
-    total += static_cast<int64_t>(ids.size());
+    total += static_cast<int64_t>(per_text[static_cast<size_t>(i)].size());
     out_offsets[i + 1] = total;
   }
+  if (out_ids && total <= capacity)
+    vr::parallel_for(n_texts, 256, [&](int64_t i) {
+      const std::vector<int32_t>& ids = per_text[static_cast<size_t>(i)];
+      if (!ids.empty()) memcpy(out_ids + out_offsets[i], ids.data(), ids.size() * sizeof(int32_t));
+    });
   *needed = total;
   if (total > capacity) {
     vr::set_error("output buffer holds %lld ids, %lld needed", static_cast<long long>(capacity), static_cast<long long>(total));
