@@ -121,3 +121,50 @@ def test_encode_is_batch_invariant_and_chunked(gpu):
     for i in (0, 57, 199, 399, 2199):
         one = _encode(shape, pooling, w, [seqs[i]])
         assert np.array_equal(one[0], all_out[i])
+
+
+def test_small_batches_replayed_as_graphs_are_bit_identical(gpu):
+    """A small forward pass is captured into a hipGraph the second time its shape is seen
+    (encoder.hip, encoder_encode). Eager, captured and replayed runs must agree bit for bit, for the
+    same input and for other inputs of the same shape (token count, sequence count, longest length)."""
+    from voitta_rag_amd import Engine
+    from voitta_rag_amd import encoder as enc
+
+    base, pooling = obert.SHAPES["bge-base-en-v1.5"]
+    shape = obert.BertShape(2, base.hidden, base.heads, base.intermediate, vocab=400, max_pos=128)
+    w = obert.random_weights(shape, 21)
+    rng = np.random.default_rng(4)
+
+    def batch(lens):
+        seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+        off = np.zeros(len(seqs) + 1, np.int32)
+        off[1:] = np.cumsum(lens)
+        return np.concatenate(seqs), off
+
+    def engine():
+        e = Engine(shape.hidden)
+        enc.load_encoder(e, enc.BertDesc(shape.layers, shape.hidden, shape.heads, shape.intermediate, vocab=shape.vocab,
+                                         max_pos=shape.max_pos, pooling=pooling, precision="f16"), w)
+        return e
+
+    e = engine()
+    a_ids, a_off = batch([12])
+    b_ids, b_off = batch([12])            # same shape, other tokens
+    c_ids, c_off = batch([7, 12, 3])
+    d_ids, d_off = batch([12, 3, 7])      # same (T, n_seq, max_len), other offsets
+    first = {k: enc.encode(e, *v) for k, v in (("a", (a_ids, a_off)), ("c", (c_ids, c_off)))}      # eager
+    second = {k: enc.encode(e, *v) for k, v in (("a", (a_ids, a_off)), ("c", (c_ids, c_off)))}     # captured + launched
+    third = {k: enc.encode(e, *v) for k, v in (("a", (a_ids, a_off)), ("c", (c_ids, c_off)))}      # replayed
+    for k in first:
+        assert np.array_equal(first[k], second[k]) and np.array_equal(first[k], third[k])
+    got_b, got_d = enc.encode(e, b_ids, b_off), enc.encode(e, d_ids, d_off)                         # replays of a's / c's graph
+    fresh = engine()
+    assert np.array_equal(got_b, enc.encode(fresh, b_ids, b_off))                                   # eager in a fresh engine
+    assert np.array_equal(got_d, enc.encode(fresh, d_ids, d_off))
+    # a big batch reallocates the workspace (graphs are dropped), then the small shape works again
+    big_ids, big_off = batch([100] * 40)
+    enc.encode(e, big_ids, big_off)
+    assert np.array_equal(enc.encode(e, a_ids, a_off), first["a"])
+    assert np.array_equal(enc.encode(e, a_ids, a_off), first["a"])
+    e.close()
+    fresh.close()

@@ -20,6 +20,9 @@
 
 #include "engine_internal.h"
 
+#include <map>
+#include <tuple>
+
 #include <algorithm>
 #include <cmath>
 
@@ -52,7 +55,29 @@ struct Encoder {
   DevArray<int32_t> ids, cu;
   DevArray<float> out;
   DevArray<float> skinny_ws;  // K-slice partial sums of gemm_f16_skinny_kernel
+  // hipGraphs of small forward passes (a query, a handful of sequences): ~135 launches of a few
+  // microseconds of work each are launch-bound; replayed as one graph they are not
+  struct GraphKey {
+    int T, n_seq, max_len;
+    const void *ids, *cu, *out;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(T, n_seq, max_len, ids, cu, out) < std::tie(o.T, o.n_seq, o.max_len, o.ids, o.cu, o.out);
+    }
+  };
+  struct GraphEntry {
+    int seen = 0;
+    bool bad = false;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::map<GraphKey, GraphEntry> graphs;
 };
+
+// captured graphs hold raw workspace pointers: every reallocation of a buffer they touch drops them
+static void invalidate_graphs(Encoder* enc) {
+  for (auto& kv : enc->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  enc->graphs.clear();
+}
 
 // ---- elementwise / normalisation ---------------------------------------------------------------
 
@@ -1164,7 +1189,11 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   if (passes == 1 && M <= 4 * kSkinnyM && skinny_slice(K) > 0 && N % 64 == 0) {
     Encoder* enc = static_cast<Encoder*>(e->encoder);
     const int kslice = skinny_slice(K), slices = K / kslice;
-    VR_TRY(enc->skinny_ws.grow(static_cast<int64_t>(slices) * M * N, 0, s));
+    {
+      const float* before = enc->skinny_ws.p;
+      VR_TRY(enc->skinny_ws.grow(static_cast<int64_t>(slices) * M * N, 0, s));
+      if (enc->skinny_ws.p != before) invalidate_graphs(enc);  // (never during a capture: a shape runs eagerly first)
+    }
     hipLaunchKernelGGL(gemm_f16_skinny_kernel, dim3(static_cast<unsigned>(N / 64), static_cast<unsigned>(slices), static_cast<unsigned>((M + kSkinnyM - 1) / kSkinnyM)),
                        dim3(256), 0, s, Ah, Wh, enc->skinny_ws.p, M, N, K, kslice);
     const unsigned eb = static_cast<unsigned>((static_cast<int64_t>(M) * N / 4 + 255) / 256);
@@ -1551,6 +1580,7 @@ void encoder_release(vr_engine* e) {
   enc->ids.release();
   enc->cu.release();
   enc->skinny_ws.release();
+  invalidate_graphs(enc);
   enc->out.release();
   delete enc;
   e->encoder = nullptr;
@@ -1619,7 +1649,8 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
 static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   if (tokens <= enc->ws_tokens) return 0;
   VR_HIP(hipStreamSynchronize(e->stream));
-  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs}) {
+  invalidate_graphs(enc);
+  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs, &enc->lnstat}) {
     if (*p) {
       enc->owned.erase(std::remove(enc->owned.begin(), enc->owned.end(), *p), enc->owned.end());
       (void)hipFree(*p);
@@ -1876,8 +1907,43 @@ int encoder_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int
       ++seq1;
     }
     VR_TRY(ensure_workspace(e, enc, std::max<int64_t>(T, 1024)));
-    VR_TRY(forward_chunk(e, enc, ids_dev, cu_dev, n_seq, seq0, seq1, cu_host[static_cast<size_t>(seq0)],
-                         static_cast<int>(T), max_len, 4.0 * H * len2, out_dev));
+    // A small forward pass (one chunk, <= 1024 tokens) is launch-bound: the second time a shape is seen
+    // it is captured into a hipGraph and replayed from then on. Only on the engine's own stream (a
+    // caller's stream may be under capture itself) and with the HIP-event profiler off.
+    static const bool graphs_on = !(getenv("VR_ENCODE_GRAPH") && atoi(getenv("VR_ENCODE_GRAPH")) == 0);
+    const bool graphable = graphs_on && seq0 == 0 && seq1 == n_seq && T <= 1024 && e->stream == e->own_stream &&
+                           !prof_on(e);
+    bool done = false;
+    if (graphable) {
+      if (enc->graphs.size() > 256) invalidate_graphs(enc);  // (shapes are few in practice; start over rather than track recency)
+      Encoder::GraphEntry& g = enc->graphs[Encoder::GraphKey{static_cast<int>(T), n_seq, max_len, ids_dev, cu_dev, out_dev}];
+      if (!g.exec && !g.bad && g.seen >= 1) {
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int rc = forward_chunk(e, enc, ids_dev, cu_dev, n_seq, seq0, seq1, 0, static_cast<int>(T), max_len,
+                                       4.0 * H * len2, out_dev);
+          hipGraph_t graph = nullptr;
+          const hipError_t end = hipStreamEndCapture(e->stream, &graph);
+          if (rc != 0 || end != hipSuccess || !graph ||
+              hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            g.exec = nullptr;
+            g.bad = true;  // this shape runs eagerly from now on
+          }
+          if (graph) (void)hipGraphDestroy(graph);
+          (void)hipGetLastError();
+        } else {
+          g.bad = true;
+          (void)hipGetLastError();
+        }
+      }
+      if (g.exec) {
+        VR_HIP(hipGraphLaunch(g.exec, e->stream));
+        done = true;
+      }
+      ++g.seen;
+    }
+    if (!done)
+      VR_TRY(forward_chunk(e, enc, ids_dev, cu_dev, n_seq, seq0, seq1, cu_host[static_cast<size_t>(seq0)],
+                           static_cast<int>(T), max_len, 4.0 * H * len2, out_dev));
     seq0 = seq1;
   }
   if (out_mem == VR_MEM_HOST) {

@@ -268,6 +268,7 @@ int encoder_hidden(vr_engine* e);  // 0 when no encoder is loaded
 // ---- profile.hip: HIP-event timing of one launch (no-ops unless vr_profile(e, 1))
 void prof_begin(vr_engine* e, int kernel_class, double work);
 void prof_end(vr_engine* e);
+bool prof_on(vr_engine* e);  // HIP-event profiling active (kernels must then not be captured into graphs)
 void prof_release(vr_engine* e);
 
 // ---- filter.hip

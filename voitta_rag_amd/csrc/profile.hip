@@ -22,6 +22,11 @@ struct Profiler {
 
 static Profiler* prof(vr_engine* e) { return static_cast<Profiler*>(e->profiler); }
 
+bool prof_on(vr_engine* e) {
+  Profiler* p = prof(e);
+  return p && p->on;
+}
+
 void prof_begin(vr_engine* e, int cls, double work) {
   Profiler* p = prof(e);
   if (!p || !p->on) return;
