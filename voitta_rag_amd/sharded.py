@@ -8,7 +8,8 @@ the multi-GPU form of VectorStoreService.search (:560-697):
   sparse  IDF must be collection-wide: all_reduce(sum) of the query terms' document frequencies
           and of N, weights q_t * idf_t computed once (vr_idf), shards score with given weights
   hybrid  min-max fusion runs on the MERGED top-3*limit lists (:659-689), never per shard
-Messages are k * 16 bytes per rank per query — latency-bound, so one flat all_gather per list.
+Messages are k * 16 bytes per rank per list — latency-bound, so a hybrid query sends both of its lists in one
+flat all_gather (after the all_reduce of the query terms' statistics).
 
 Global row id of local row r on rank p: r * world + p (order-preserving per shard, unique).
 Ties in score resolve to the lower global id.
@@ -49,21 +50,31 @@ class ShardedSearcher:
     # ---- collectives ---------------------------------------------------------------------------
     def _merge(self, rows: np.ndarray, scores: np.ndarray, k: int):
         """all_gather this rank's (<= k) results, return the global top-k (gids, scores)."""
-        buf = np.full(2 * k, -1, np.int64)
-        c = len(rows)
-        buf[:c] = self.global_ids(rows)
-        buf[k:k + c] = scores.astype(np.float32).view(np.int32).astype(np.int64)
+        return self._merge_lists([(rows, scores)], k)[0]
+
+    def _merge_lists(self, lists, k: int):
+        """One all_gather for several result lists of this rank (each <= k rows): returns the global
+        top-k (gids, scores) of every list. The hybrid search sends its dense and its sparse list together."""
+        n = len(lists)
+        buf = np.full(n * 2 * k, -1, np.int64)
+        for j, (rows, scores) in enumerate(lists):
+            c = len(rows)
+            base = j * 2 * k
+            buf[base:base + c] = self.global_ids(rows)
+            buf[base + k:base + k + c] = scores.astype(np.float32).view(np.int32).astype(np.int64)
         mine = torch.from_numpy(buf).to(self.comm_device)
-        out = torch.empty(self.world * 2 * k, dtype=torch.int64, device=self.comm_device)
+        out = torch.empty(self.world * n * 2 * k, dtype=torch.int64, device=self.comm_device)
         dist.all_gather_into_tensor(out, mine, group=self.group)
-        allr = out.cpu().numpy().reshape(self.world, 2, k)
-        gids = allr[:, 0, :].reshape(-1)
-        sc = allr[:, 1, :].reshape(-1).astype(np.int32).view(np.float32)
-        keep = gids >= 0
-        gids, sc = gids[keep], sc[keep]
-        order = np.lexsort((gids, -sc.astype(np.float64)))  # score descending, then gid ascending
-        order = order[:k]
-        return gids[order], sc[order]
+        allr = out.cpu().numpy().reshape(self.world, n, 2, k)
+        merged = []
+        for j in range(n):
+            gids = allr[:, j, 0, :].reshape(-1)
+            sc = allr[:, j, 1, :].reshape(-1).astype(np.int32).view(np.float32)
+            keep = gids >= 0
+            gids, sc = gids[keep], sc[keep]
+            order = np.lexsort((gids, -sc.astype(np.float64)))[:k]  # score descending, then gid ascending
+            merged.append((gids[order], sc[order]))
+        return merged
 
     def global_sparse_weights(self, q_idx, q_val):
         """q_t * idf_t from all-reduced statistics -> (ids sorted unique, weights f32)."""
@@ -93,11 +104,20 @@ class ShardedSearcher:
         return self._merge(rows, scores, k)
 
     def search_hybrid(self, query, q_idx, q_val, limit: int, sparse_weight: float = 0.1, flt=None):
-        """-> (gids, fused scores f64, from_dense) exactly as one engine holding every shard would."""
+        """-> (gids, fused scores f64, from_dense) exactly as one engine holding every shard would.
+        Two collectives per query: the all_reduce of the query terms' statistics, then ONE all_gather that
+        carries this shard's dense and sparse lists together."""
         k = 3 * limit  # prefetch_limit, vector_store.py:636
-        d_ids, d_sc = self.search_dense(query, k, flt)
-        if len(np.atleast_1d(q_idx)) > 0:
-            s_ids, s_sc = self.search_sparse(q_idx, q_val, k, flt)
+        empty = (np.zeros(0, np.int64), np.zeros(0, np.float32))
+        d_local = self.local.search_dense(np.asarray(query, np.float32).reshape(1, -1), k, flt)[0]
+        s_local = empty
+        have_sparse = len(np.atleast_1d(q_idx)) > 0
+        if have_sparse:
+            ids, w = self.global_sparse_weights(q_idx, q_val)
+            if len(ids):
+                s_local = self.local.search_sparse(ids, w, k, flt, weights_given=True)
+        if have_sparse:
+            (d_ids, d_sc), (s_ids, s_sc) = self._merge_lists([d_local, s_local], k)
         else:
-            s_ids, s_sc = np.zeros(0, np.int64), np.zeros(0, np.float32)
+            (d_ids, d_sc), (s_ids, s_sc) = self._merge_lists([d_local], k)[0], empty
         return fuse_minmax(d_ids, d_sc, s_ids, s_sc, limit, sparse_weight, True)
