@@ -826,14 +826,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     glds16(g_w3 + (k0), d + 256 * 64 + 192 * 64);                   \
   } while (0)
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 
-  // fragments: lane l supplies row (l & 31), k = 8*(l >> 5) + j of a 16-deep step.
-  // PASSES 3: k8-group g = 2*kk + (l >> 5) of the 32-deep tile, hi = chunk 2g, lo = chunk 2g + 1.
-  // PASSES 1: chunk 2*kk + (l >> 5) of the 64-deep tile.
-  const int frow = lane & 31;
+  // v_mfma_f32_16x16x32_f16 fragments: lane l supplies row (l & 15), k = 8*(l >> 4) + j of a 32-deep step
+  // (the chip holds a higher clock on this shape than on 32x32x16 at the same work per cycle).
+  // PASSES 3: k8-group g = l >> 4 of the 32-deep tile, hi = chunk 2g, lo = chunk 2g + 1.
+  // PASSES 1: chunk 4*kk + (l >> 4) of the 64-deep tile.
+  const int frow = lane & 15;
   const int fsw = (frow >> 1) & 7;
-  const int fhalf = lane >> 5;
+  const int fq = lane >> 4;
   const int pa = (wm * 128 + frow) * 64;
   const int pw = 256 * 64 + (wn * 64 + frow) * 64;
 
@@ -845,11 +846,9 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   __syncthreads();
   while (true) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the next tile of this block: its first K-tile is loaded during this tile's LAST K-tile, so only the
   // first tile of a block pays a prologue, and this tile's stores drain under the next main loop
   const int next = tile + G;
@@ -864,41 +863,37 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
     // every row of MFMA tiles, where the partner wave of the SIMD fills the gap.
     half_t* nd = l_dst + ((par + kt + 1) & 1) * kStageHalfs;
     const int nk0 = kt + 1 < nk ? (kt + 1) * kTileHalfs : 0;  // K-tile 0 of the next tile (or, at the very end, a harmless re-load)
-    constexpr int kSteps = PASSES == 3 ? 2 : 4;  // 16-deep MFMA steps per K-tile
+    constexpr int kSteps = PASSES == 3 ? 1 : 2;  // 32-deep MFMA steps per K-tile
 #pragma unroll
     for (int kk = 0; kk < kSteps; ++kk) {
-      f16x8 ah[4], al[4], wh[2], wl[2];
-      if (PASSES == 3) {
-        const int fh = ((2 * (2 * kk + fhalf)) ^ fsw) * 8, fl = ((2 * (2 * kk + fhalf) + 1) ^ fsw) * 8;
+      // the four weight fragments stay resident for the step; activation fragments are read one row
+      // of tiles ahead of their MFMAs
+      f16x8 wh[4], wl[4], ah[2], al[2];
+      const int fh = PASSES == 3 ? ((2 * fq) ^ fsw) * 8 : ((4 * kk + fq) ^ fsw) * 8;
+      const int fl = ((2 * fq + 1) ^ fsw) * 8;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
-          wl[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fl);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
-          al[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fl);
-        }
-      } else {
-        const int fh = ((2 * kk + fhalf) ^ fsw) * 8;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 32 * 64 + fh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const f16x8*>(st + pa + i * 32 * 64 + fh);
+      for (int j = 0; j < 4; ++j) {
+        wh[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fh);
+        if (PASSES == 3) wl[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fl);
       }
+      ah[0] = *reinterpret_cast<const f16x8*>(st + pa + fh);
+      if (PASSES == 3) al[0] = *reinterpret_cast<const f16x8*>(st + pa + fl);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
+        if (i + 1 < 8) {
+          ah[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(st + pa + (i + 1) * 16 * 64 + fh);
+          if (PASSES == 3) al[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(st + pa + (i + 1) * 16 * 64 + fl);
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i & 1], wh[j], acc[i][j], 0, 0, 0);
           if (PASSES == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i & 1], wl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i & 1], wh[j], acc[i][j], 0, 0, 0);
           }
         }
-        if (kk < 2) {
-          const int piece = kk * 4 + i;  // compile-time after unrolling
+        if (kk == 0) {
+          const int piece = i;  // compile-time after unrolling
           const half_t* src = piece == 0 ? g_a0 : piece == 1 ? g_a1 : piece == 2 ? g_a2 : piece == 3 ? g_a3
                             : piece == 4 ? g_w0 : piece == 5 ? g_w1 : piece == 6 ? g_w2 : g_w3;
           glds16(src + nk0, nd + (piece >> 2) * 256 * 64 + (piece & 3) * 64 * 64);
@@ -944,15 +939,14 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   };
   if (kResidual) fetch_residual(0, r4[0], st4[0]);
 #pragma unroll
-  for (int pc = 0; pc < 8; ++pc) {  // piece pc = rows 16 pc .. 16 pc + 15 of the wave's 128: MFMA tile i, half h
-    const int i = pc >> 1, h = pc & 1;
+  for (int pc = 0; pc < 8; ++pc) {  // piece pc = rows 16 pc .. 16 pc + 15 of the wave's 128 = MFMA tile row pc
     const int row0 = bm + wm * 128 + 16 * pc + (lane >> 4);  // + 4 * it
     if (kResidual && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][8 * h + r];
+      for (int r = 0; r < 4; ++r)
+        stage[(4 * (lane >> 4) + r) * SLD + j * 16 + (lane & 15)] = acc[pc][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     auto emit = [&](int it) {
