@@ -196,6 +196,29 @@ int vr_bm25_tokenize(const char* const* texts, const int64_t* lens, int64_t n,
 /* Snowball English (Porter2) stem of one lower-case UTF-8 word; NUL-terminated into out. */
 int vr_porter2_stem(const char* word, int64_t len, char* out, int64_t cap);
 
+/* ---- chunking: replaces ChunkingService.chunk_text (src/voitta/services/chunking.py:33-241,
+ * called from services/indexing.py:380,515), the step in front of the path. Host
+ * only, one document per host thread. texts[i]: text_lens[i] bytes of UTF-8. chunk_size and
+ * chunk_overlap count CHARACTERS (code points, Python's len()). strategy: VR_CHUNK_*; any other
+ * value chunks recursively, as the reference does for an unknown name. The call fails when
+ * chunk_overlap >= chunk_size AND some text falls through to the fixed-size windows: the
+ * reference's window loop never advances there (chunking.py:187) and hangs.
+ * The result object holds, until vr_chunks_free:
+ *   doc_off   n_texts + 1  chunk index range of each text (an empty / all-blank text has none)
+ *   span      2 per chunk  (start_char, end_char) code-point offsets exactly as the reference
+ *                          reports them (for overlapped chunks it does not advance start_char)
+ *   text_off  n_chunks + 1 byte offsets into `text`, the stripped chunk texts back to back (UTF-8)
+ * Chunk.index is the position inside its text's range. */
+#define VR_CHUNK_RECURSIVE 0
+#define VR_CHUNK_SENTENCE 1
+#define VR_CHUNK_FIXED 2
+typedef struct vr_chunks vr_chunks;
+int vr_chunk_texts(const char* const* texts, const int64_t* text_lens, int64_t n_texts, int32_t chunk_size,
+                   int32_t chunk_overlap, int32_t strategy, vr_chunks** out);
+int vr_chunks_view(const vr_chunks* c, int64_t* n_chunks, const int64_t** doc_off, const int64_t** span,
+                   const int64_t** text_off, const char** text);
+void vr_chunks_free(vr_chunks* c);
+
 /* ---- fused indexing step: the three starred calls of IndexingService._index_file_standard
  * (src/voitta/services/indexing.py:527-530,560) — embed_texts, sparse embed_texts, store_chunks —
  * without leaving HBM: encode (vr_encode) -> BM25 tf (vr_bm25_tf) -> store (vr_upsert).

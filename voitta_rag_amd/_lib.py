@@ -94,6 +94,11 @@ SIGNATURES = {
     "vr_wordpiece_destroy": (None, [_vp]),
     "vr_wordpiece_encode": (C.c_int, [_vp, C.POINTER(C.c_char_p), _i64p, C.c_int64, C.c_int32, _i64p, _i32p, C.c_int64,
                                      _i64p]),
+    "vr_chunk_texts": (C.c_int, [C.POINTER(C.c_char_p), _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                C.POINTER(_vp)]),
+    "vr_chunks_view": (C.c_int, [_vp, _i64p, C.POINTER(_i64p), C.POINTER(_i64p), C.POINTER(_i64p),
+                                C.POINTER(C.POINTER(C.c_char))]),
+    "vr_chunks_free": (None, [_vp]),
     "vr_bm25_tf": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp]),
     "vr_bm25_tokenize": (C.c_int, [C.POINTER(C.c_char_p), _i64p, C.c_int64, _i64p, _i32p, C.c_int64, _i64p]),
     "vr_porter2_stem": (C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]),

@@ -14,6 +14,9 @@ class Settings:
         self.embedding_model: str = os.getenv("EMBEDDING_MODEL", "intfloat/e5-base-v2")    # config.py:33
         self.embedding_dimension: int = int(os.getenv("EMBEDDING_DIMENSION", "768"))       # config.py:34
         self.embedding_device: str = os.getenv("EMBEDDING_DEVICE", "auto")                 # config.py:36
+        self.chunk_size: int = int(os.getenv("CHUNK_SIZE", "512"))                         # config.py:39
+        self.chunk_overlap: int = int(os.getenv("CHUNK_OVERLAP", "50"))                    # config.py:40
+        self.chunking_strategy: str = os.getenv("CHUNKING_STRATEGY", "recursive")          # config.py:41
         self.sparse_weight: float = float(os.getenv("SPARSE_WEIGHT", "0.1"))               # config.py:44
         self.mcp_search_limit: int = int(os.getenv("MCP_SEARCH_LIMIT", "20"))              # config.py:72
         # native additions

@@ -17,7 +17,10 @@ import sys
 import types
 
 
-def install() -> None:
+def install(chunking: bool = True) -> None:
+    """chunking=True also swaps ChunkingService / get_chunking_service (services/chunking.py:19-246,
+    obtained by IndexingService at indexing.py:187) for the native chunker."""
+    from . import chunking as native_chunking
     from . import embedding, sparse_embedding, vector_store
 
     mapping = {
@@ -27,6 +30,8 @@ def install() -> None:
         "voitta.services.vector_store": (vector_store, ["VectorStoreService", "get_vector_store", "ChunkMetadata",
                                                         "StoredChunk"]),
     }
+    if chunking:
+        mapping["voitta.services.chunking"] = (native_chunking, ["ChunkingService", "get_chunking_service", "Chunk"])
     for name, (native, attrs) in mapping.items():
         try:
             mod = importlib.import_module(name)
