@@ -405,9 +405,9 @@ def main():
             # three f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOP/s is the dense f16 peak / 3.
             "roofline": {
                 "kernel": {"f32": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-                           "f16x3": "vr::gemm_f16x3_256_kernel<EPI, 3> (v_mfma_f32_32x32x16_f16, 3 passes per "
+                           "f16x3": "vr::gemm_f16x3_256_kernel<EPI, 3> (v_mfma_f32_16x16x32_f16, 3 passes per "
                                     "product; 256x256 tiles)",
-                           "f16": "vr::gemm_f16x3_256_kernel<EPI, 1> (v_mfma_f32_32x32x16_f16, one pass; "
+                           "f16": "vr::gemm_f16x3_256_kernel<EPI, 1> (v_mfma_f32_16x16x32_f16, one pass; "
                                   "256x256x64 tiles)"}[args.precision],
                 "bound": "mfma",
                 "achieved": round(gemm_tf, 2),

@@ -324,6 +324,40 @@ class VectorStoreService:
         logger.info(f"Stored {n} chunks in the native engine")
         return ids
 
+    def index_chunks(self, texts: list[str], metadatas: list[ChunkMetadata], wp_ids, wp_off,
+                     bm_ids=None, bm_off=None) -> list[str]:
+        """The fused form of the three calls of IndexingService._index_file_standard —
+        ``embedder.embed_texts`` + ``sparse_embedder.embed_texts`` + ``store_chunks``
+        (indexing.py:527-530,560) — for a caller that hands over token ids instead of vectors: WordPiece
+        ids (``wp_ids`` / ``wp_off``, [CLS] … [SEP] per chunk) and hashed BM25 stems (``bm_ids`` /
+        ``bm_off``, or None for a dense-only store). Encode, tf weighting and the append run in ONE engine
+        call (vr_index_batch) and nothing leaves HBM; the stored rows, payloads and scores are those the
+        three calls would have produced. Needs the encoder loaded into this store's engine."""
+        n = len(texts)
+        if n == 0:
+            return []
+        assert len(metadatas) == n
+        col = self._col
+        with col.lock:
+            folder = np.array([col.folder_id(m.folder_path, True) for m in metadatas], np.int32)
+            ifolder = np.array([col.index_folder_id(m.index_folder, True) for m in metadatas], np.int32)
+            created = np.array([VR_TS_ABSENT if m.source_created_at is None else int(m.source_created_at)
+                                for m in metadatas], np.int64)
+            modified = np.array([VR_TS_ABSENT if m.source_modified_at is None else int(m.source_modified_at)
+                                 for m in metadatas], np.int64)
+            first = self.client.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
+                                            created=created, modified=modified)
+            assert first == len(col.payload), "host table and engine rows diverged"
+            ids = []
+            for i, (text, metadata) in enumerate(zip(texts, metadatas)):
+                point_id = str(uuid.uuid4())
+                ids.append(point_id)
+                col.ids.append(point_id)
+                col.payload.append(self._payload_of(text, metadata))
+                col.row_of[point_id] = first + i
+                col.rows_by_file.setdefault(metadata.file_path, []).append(first + i)
+        return ids
+
     # ---- deletes / ACL ----------------------------------------------------------------------------
     def delete_by_file(self, file_path: str) -> int:
         col = self._col
