@@ -422,7 +422,9 @@ def main():
                 "share_of_step_time": round(gemm_ms * 1e-3 / dt, 4),
             },
             "roofline_search": {
-                "kernel": "vr::prefilter_scan_kernel (v_mfma_f32_16x16x32_f16 streaming scan of the f16 shadow "
+                "kernel": ("vr::prefilter_scan_kernel (v_mfma_f32_16x16x32_f16 streaming scan of the f16 shadow "
+                           if os.environ.get("VR_PREFILTER") == "f16" or MODEL["hidden"] % 64 else
+                           "vr::prefilter_scan8_kernel (v_mfma_i32_16x16x64_i8 streaming scan of the int8 shadow ") +
                           "corpus, stage 1 of the exact two-stage search; timed with the sparse leg running "
                           "beside it on the second stream)",
                 "bound": "hbm",
@@ -430,7 +432,7 @@ def main():
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": round(scan_gbps / PEAK_HBM_GBPS, 4),
-                "traffic": pmc_traffic("prefilter_scan_kernel"),
+                "traffic": pmc_traffic("prefilter_scan_kernel") or pmc_traffic("prefilter_scan8_kernel"),
                 "two_stage": engine.stats(),
                 "algorithmic_bytes_per_launch": round(scan_bytes / max(scan_n, 1)),
                 "launches": scan_n,

@@ -196,13 +196,19 @@ def test_rows_without_sparse_vectors_and_empty_engine(gpu):
     e.close()
 
 
+@pytest.mark.parametrize("shadow", ["int8", "f16"])
 @pytest.mark.parametrize("dim,n", [(768, 20000), (384, 9000), (1024, 5000), (64, 6000), (96, 5000)])
-def test_two_stage_dense_search_is_bit_identical(gpu, dim, n):
-    """Stores with dim % 32 == 0 and >= 4096 rows answer single-query dense searches through the
-    f16 prefilter + exact re-score (prefilter.hip). Rows, scores and order must equal the oracle's —
-    and therefore the one-stage scan's — bit for bit, with filters and tombstones in play."""
+def test_two_stage_dense_search_is_bit_identical(gpu, dim, n, shadow, monkeypatch):
+    """Stores with dim % 32 == 0 and >= 4096 rows answer single-query dense searches through a
+    reduced-precision shadow scan + exact re-score (prefilter.hip): int8 with a scale per row when
+    dim % 64 == 0 (unless VR_PREFILTER=f16), f16 otherwise. Rows, scores and order must equal the
+    oracle's — and therefore the one-stage scan's — bit for bit, with filters and tombstones in play."""
     from voitta_rag_amd import SearchFilter
 
+    if shadow == "f16":
+        monkeypatch.setenv("VR_PREFILTER", "f16")
+    elif dim % 64:
+        pytest.skip("the int8 shadow needs dim % 64 == 0; this dimension always takes the f16 one")
     rng = np.random.default_rng(dim * 7 + n)
     x = _corpus(rng, n, dim)
     x[100:140] = x[100] + rng.standard_normal((40, dim)).astype(np.float32) * 1e-3  # a tight cluster
@@ -243,9 +249,9 @@ def test_two_stage_dense_search_is_bit_identical(gpu, dim, n):
 
 
 def test_two_stage_overflow_falls_back_to_exact_scan(gpu):
-    """A corpus of near-duplicates cannot be separated by the f16 bounds: every row is a candidate,
-    the re-score budget overflows and the search must transparently redo the one-stage scan."""
-    dim, n = 128, 12000
+    """A corpus of near-duplicates cannot be separated by the shadow's bounds: every row is a candidate,
+    the re-score budget (16384 tiles) overflows and the search must transparently redo the one-stage scan."""
+    dim, n = 128, 300000
     rng = np.random.default_rng(1)
     base = rng.standard_normal(dim).astype(np.float32)
     x = (base[None, :] + rng.standard_normal((n, dim)).astype(np.float32) * 2e-4).astype(np.float32)
@@ -258,5 +264,33 @@ def test_two_stage_overflow_falls_back_to_exact_scan(gpu):
     gr, gs = e.search_dense(q[None], 10)[0]
     assert np.array_equal(gr, wr) and np.array_equal(gs, ws)
     st = e.stats()
-    assert st["two_stage"] == 1 and st["fallback"] == 1 and st["last_candidates"] > 4096
+    assert st["two_stage"] == 1 and st["fallback"] == 1 and st["last_candidates"] > 16384 * 16
+    e.close()
+
+
+@pytest.mark.parametrize("shadow", ["int8", "f16"])
+def test_two_stage_rescoring_by_tile_absorbs_a_tight_cluster(gpu, shadow, monkeypatch):
+    """20,000 stored rows within 1e-3 of each other (what a random-init encoder produces, and what the int8
+    bounds cannot separate) among random rows: tens of thousands of candidates, but they share 1,250
+    tiles, so the query is answered by the two-stage path without a fallback — and bit-exactly."""
+    if shadow == "f16":
+        monkeypatch.setenv("VR_PREFILTER", "f16")
+    dim, n = 256, 60000
+    rng = np.random.default_rng(3)
+    x = _corpus(rng, n, dim)
+    base = rng.standard_normal(dim).astype(np.float32)
+    x[30000:50000] = base[None, :] + rng.standard_normal((20000, dim)).astype(np.float32) * 1e-3
+    e = _engine(dim)
+    e.upsert(x)
+    xh = ocore.cosine_preprocess(x)
+    for q in (base + rng.standard_normal(dim).astype(np.float32) * 1e-3, x[7], x[31234]):
+        sc = ocore.dense_scores(ocore.cosine_preprocess(q[None]), xh)[0]
+        for k in (10, 64):
+            wr, ws = ocore.topk(sc, k)
+            gr, gs = e.search_dense(q[None], k)[0]
+            assert np.array_equal(gr, wr) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    st = e.stats()
+    assert st["two_stage"] == 6 and st["fallback"] == 0
+    if shadow == "int8":
+        assert st["last_candidates"] > 4096  # the last query sits inside the cluster
     e.close()

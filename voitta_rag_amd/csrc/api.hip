@@ -35,8 +35,10 @@ int ensure_rows(vr_engine* e, int64_t need) {
   const int64_t keep_tiles = (keep_rows + kTileRows - 1) / kTileRows;
   VR_TRY(e->corpus.grow(ncap * e->dim, keep_tiles * kTileRows * e->dim, e->stream));
   if (e->prefilter) {
-    VR_TRY(e->corpus16.grow(ncap * e->dim, keep_tiles * kTileRows * e->dim, e->stream));
+    const int per_u16 = e->prefilter8 ? 2 : 1;  // shadow elements per uint16 of storage
+    VR_TRY(e->corpus16.grow(ncap * e->dim / per_u16, keep_tiles * kTileRows * e->dim / per_u16, e->stream));
     VR_TRY(e->row_err.grow(ncap, keep_tiles * kTileRows, e->stream));
+    if (e->prefilter8) VR_TRY(e->row_scale.grow(ncap, keep_tiles * kTileRows, e->stream));
   }
   VR_TRY(e->live.grow(ncap, keep_rows, e->stream));
   VR_TRY(e->folder.grow(ncap, keep_rows, e->stream));
@@ -155,6 +157,12 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
   e->dim = cfg->dim;
   e->kblocks = cfg->dim / kTileK;
   e->prefilter = (cfg->dim % 32 == 0) && !(cfg->flags & VR_ENGINE_NO_PREFILTER);
+  {
+    // shadow format of the two-stage search: int8 + row scale where the MFMA tiling allows, else f16;
+    // VR_PREFILTER=f16 keeps the f16 shadow (tighter bounds: fewer re-scores on corpora of near-duplicates)
+    const char* mode = getenv("VR_PREFILTER");
+    e->prefilter8 = e->prefilter && cfg->dim % 64 == 0 && !(mode && strcmp(mode, "f16") == 0);
+  }
   // a blocking stream: it orders itself against the legacy null stream, so device buffers
   // produced by a framework on its default stream are safe to hand in without extra events
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamDefault) != hipSuccess) {
@@ -196,6 +204,7 @@ void vr_engine_destroy(vr_engine* e) {
   e->corpus.release();
   e->corpus16.release();
   e->row_err.release();
+  e->row_scale.release();
   e->upper.release();
   e->cand_rows.release();
   e->cand_keys.release();

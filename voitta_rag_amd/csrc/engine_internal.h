@@ -99,7 +99,11 @@ constexpr size_t kPinDenseKeys = 128 * 1024;   // uint64[16][kMaxK]
 constexpr size_t kPinSparseKeys = 192 * 1024;  // uint64[kMaxK]
 constexpr size_t kPinCandCount = 256 * 1024;   // int32: candidates of the last two-stage dense search
 constexpr size_t kPinnedBytes = 1 << 20;
-constexpr int kMaxCandidates = 4096;           // re-score budget of the two-stage dense search
+// re-score budget of the two-stage dense search: candidate TILES (16 rows, one tile read each: at most
+// 16384 x 48 KiB = 0.8 GB at D = 768, a quarter of the one-stage scan it replaces). The candidate-row count
+// the device reports is at most kMaxCandidates, or INT32_MAX when the tile budget overflowed.
+constexpr int kMaxCandTiles = 16384;
+constexpr int kMaxCandidates = kMaxCandTiles * 16;
 
 }  // namespace vr
 
@@ -125,6 +129,11 @@ struct vr_engine {
   // and not disabled: [row/16][k/32][lane = (k%32)/8*16 + row%16][8 halfs], plus the exact
   // rounding residual |x - f16(x)|_2 of every row.
   bool prefilter = false;
+  // int8 form of the shadow (dim % 64 == 0, unless VR_PREFILTER=f16): corpus16 then holds
+  // [row/16][k/64][lane = (k%64)/16*16 + row%16][16 int8] with one scale per row (row_scale), and
+  // row_err the exact residual |x - scale * int8(x)|_2. Half the bytes of the f16 shadow again.
+  bool prefilter8 = false;
+  vr::DevArray<float> row_scale;
   int64_t stat_two_stage = 0;   // single-query dense searches served by the two-stage path
   int64_t stat_fallback = 0;    // ... of which overflowed the re-score budget and were redone one-stage
   vr::DevArray<uint16_t> corpus16;
