@@ -60,12 +60,13 @@ typedef struct vr_config {
 
 /* vr_config.flags.
  * By default a single-query dense search over a store with dim % 32 == 0 runs in two stages:
- * an f16 shadow copy of the corpus (1/2 of the bytes) is scanned with the f16 MFMA, a rigorous
- * per-row error bound (the row's exact rounding residual, Cauchy-Schwarz) turns the approximate
+ * a reduced-precision shadow copy of the corpus is scanned on the matrix cores — int8 with one
+ * scale per row when dim % 64 == 0 (1/4 of the bytes, +25 % memory), f16 otherwise or when the
+ * environment has VR_PREFILTER=f16 (1/2 of the bytes, +50 % memory) — a rigorous per-row error
+ * bound (the norm of the row's quantisation residual, Cauchy-Schwarz) turns the approximate
  * scores into lower/upper bounds, and every row whose upper bound reaches the k-th best lower
  * bound is re-scored with the exact f32 chain. Results are bit-identical to the one-stage exact
- * scan (tests run both); the flag below turns the shadow copy (+50 % memory) and the first
- * stage off. */
+ * scan (tests run both); the flag below turns the shadow copy and the first stage off. */
 #define VR_ENGINE_NO_PREFILTER 1
 
 /* Search-time predicate; restates _build_filter, vector_store.py:462-530. All ids are the
@@ -315,7 +316,7 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem,
  * vr_save writes everything the device owns — tiled dense corpus, payload columns, tombstones,
  * SELL sparse index, document-frequency table — to ONE file (written to path + ".tmp", then renamed
  * over `path`); vr_load restores it into an EMPTY engine of the same dimension and rebuilds the
- * f16 shadow. Row numbers, scores and rankings after a load are identical to those before the
+ * search shadow. Row numbers, scores and rankings after a load are identical to those before the
  * save. The file is checksummed; a truncated or corrupt file is refused. Payload text, point ids
  * and the folder dictionaries belong to the host (voitta_rag_amd/vector_store.py saves them beside it). */
 int vr_save(vr_engine* e, const char* path);

@@ -78,7 +78,7 @@ class Engine:
     """One HBM-resident index on one GPU."""
 
     def __init__(self, dim: int, device: int = 0, initial_rows: int = 0, prefilter: bool = True):
-        """prefilter: keep the f16 shadow corpus and run single-query dense searches in two
+        """prefilter: keep the int8 (f16 when dim % 64 != 0 or VR_PREFILTER=f16) shadow corpus and run single-query dense searches in two
         stages (f16 scan + exact re-score; identical results, half of the bytes)."""
         self._lib = _lib.load_library()
         cfg = _lib.VrConfig()
