@@ -1,0 +1,107 @@
+"""a8 — the offline BM25 rebuild (reference: scripts/build_sparse_vectors.py:73-245): a collection stored
+dense-only is migrated into a new one with sparse vectors; ids, payloads and dense vectors carry over,
+points without text get no sparse vector, and the migrated collection answers hybrid queries exactly
+like a collection that was indexed with sparse vectors from the start."""
+import os
+
+import numpy as np
+import pytest
+
+from test_services_gpu import native, _texts  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _answers(vs, emb, sp, queries):
+    out = []
+    for q in queries:
+        qv = emb.embed_query(q)
+        for kw in ({}, {"sparse_query": sp.embed_query(q), "sparse_weight": 0.4}, {"sparse_query": sp.embed_query(q), "sparse_weight": 1.0},
+                   {"sparse_query": sp.embed_query(q), "sparse_weight": 0.4, "include_folders": ["b"]}):
+            out.append([(r.id if kw is None else (r.metadata.file_path, r.metadata.chunk_index), r.score)
+                        for r in vs.search(qv, limit=8, **kw)])
+    return out
+
+
+def _index(vs, emb, sp, texts, with_sparse):
+    from voitta_rag_amd.vector_store import ChunkMetadata
+
+    embeddings = emb.embed_texts(texts)
+    chunks = [(t, e, ChunkMetadata(file_path=f"{'ab'[i % 2]}/f{i // 10}.md", folder_path="ab"[i % 2], index_folder="ab"[i % 2],
+                                   file_name=f"f{i // 10}.md", chunk_index=i % 10, total_chunks=10, start_char=0, end_char=len(t),
+                                   indexed_at="t", source_modified_at=1_700_000_000 + i))
+              for i, (t, e) in enumerate(zip(texts, embeddings))]
+    return vs.store_chunks(chunks, sparse_vectors=sp.embed_texts(texts) if with_sparse else None)
+
+
+def test_rebuild_matches_a_collection_indexed_with_sparse_vectors(native, tmp_path, monkeypatch):  # noqa: F811
+    from voitta_rag_amd import store_registry
+    from voitta_rag_amd.build_sparse import build_sparse_vectors
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import get_vector_store
+
+    rng = np.random.default_rng(21)
+    texts = _texts(rng, 230)
+    queries = ["vector database index", "running happily", "memory bandwidth kernel", "hybrid fusion ranking"]
+
+    # the answer key: sparse vectors from the start; a few rows deleted so that the source has tombstones
+    native("mini-a")
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    _index(vs, emb, sp, texts, with_sparse=True)
+    vs.delete_by_file("a/f3.md")
+    want = _answers(vs, emb, sp, queries)
+    want_count = vs.client.count()[1]
+
+    # the source: dense only (what the reference's collection looked like before the BM25 migration)
+    index_dir = tmp_path / "index"
+    monkeypatch.setenv("VOITTA_INDEX_DIR", str(index_dir))
+    native("mini-b")
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    ids = _index(vs, emb, sp, texts, with_sparse=False)
+    vs.delete_by_file("a/f3.md")
+    assert vs.client.sparse_stats(np.array(sp.embed_query("vector")[0], np.int32))[1] == 0  # no sparse points yet
+    dense_before = _answers(vs, emb, sp, queries)[0::4]
+
+    dry = build_sparse_vectors(dry_run=True)
+    assert dry["processed"] == want_count and dry["inserted"] == 0 and vs.client.count()[1] == want_count
+
+    stats = build_sparse_vectors(batch_size=64, switch=True)
+    assert stats["target"] == "voitta_documents_v2" and stats["processed"] == stats["inserted"] == want_count
+    assert stats["skipped"] == 0 and stats["rate"] > 0
+    assert all(os.path.exists(index_dir / f"voitta_documents_v2{ext}") for ext in (".vrindex", ".payload.jsonl", ".meta.json"))
+
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    assert vs.client.count() == (want_count, want_count)  # tombstones were not copied
+    got = _answers(vs, emb, sp, queries)
+    assert got[0::4] == dense_before           # dense answers untouched by the migration
+    assert got == want                         # and everything equals the collection built with BM25 from the start
+    kept = [i for i in ids if i in vs._col.row_of]
+    assert len(kept) == want_count             # point ids carried over
+
+    # the reference's switch-over: a restart with QDRANT_COLLECTION=<target> serves the saved target
+    monkeypatch.setenv("QDRANT_COLLECTION", "voitta_documents_v2")
+    native("mini-c")
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    assert vs.collection_name == "voitta_documents_v2" and vs.client.count() == (want_count, want_count)
+    assert _answers(vs, emb, sp, queries) == want
+    store_registry.reset()
+
+
+def test_points_without_text_get_no_sparse_vector(native):  # noqa: F811
+    from voitta_rag_amd.build_sparse import build_sparse_vectors
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import get_vector_store
+
+    native()
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    texts = ["vector database", "sparse dense hybrid", "retrieval query", "index folder", "kernel memory"]
+    _index(vs, emb, sp, texts, with_sparse=False)
+    for r in (1, 2):  # payloads whose text was lost (build_sparse_vectors.py:158-165)
+        vs._col.payload[r]["text"] = ""
+    stats = build_sparse_vectors(switch=True)
+    assert (stats["processed"], stats["inserted"], stats["skipped"]) == (5, 5, 2)
+    vs = get_vector_store()
+    _, n_points = vs.client.sparse_stats(np.zeros(1, np.int32))
+    assert n_points == 3  # the IDF's N counts the three points that carry a sparse vector

@@ -46,3 +46,22 @@ def reset() -> None:
             _engine.close()
         _engine = None
         _collections.clear()
+
+
+def replace(engine, collections: dict) -> None:
+    """Install a rebuilt index as the live one (voitta_rag_amd/build_sparse.py with switch=True):
+    closes the previous engine, keeps exactly the given {name: collection} host tables."""
+    global _engine
+    with _lock:
+        old = _engine
+        _engine = engine
+        _collections.clear()
+        _collections.update(collections)
+    if old is not None and old is not engine:
+        old.close()
+
+
+def forget(name: str) -> None:
+    """Drop a host table that was registered only to be saved under its own name."""
+    with _lock:
+        _collections.pop(name, None)
