@@ -78,6 +78,11 @@ def test_rebuild_matches_a_collection_indexed_with_sparse_vectors(native, tmp_pa
     assert got == want                         # and everything equals the collection built with BM25 from the start
     kept = [i for i in ids if i in vs._col.row_of]
     assert len(kept) == want_count             # point ids carried over
+    # scripts/sync_qdrant_stats.py:29-81: the per-file aggregate the reference scrolls the collection for
+    per_file = vs.scan_file_stats()
+    assert sum(f["chunk_count"] for f in per_file.values()) == want_count and "a/f3.md" not in per_file
+    assert per_file["b/f0.md"] == {"folder_path": "b", "index_folder": "b", "chunk_count": 5, "indexed_at": "t"}
+    assert {fp: f["chunk_count"] for fp, f in per_file.items()} == vs.get_file_chunk_counts()
 
     # the reference's switch-over: a restart with QDRANT_COLLECTION=<target> serves the saved target
     monkeypatch.setenv("QDRANT_COLLECTION", "voitta_documents_v2")

@@ -535,6 +535,25 @@ class VectorStoreService:
             logger.error(f"Error getting file chunk counts: {e}")
             return {}
 
+    def scan_file_stats(self) -> dict[str, dict]:
+        """Per-file aggregate over every stored chunk: ``{file_path: {folder_path, index_folder,
+        chunk_count, indexed_at}}`` — what the reference's ``scripts/sync_qdrant_stats.py:29-81``
+        (``scan_qdrant``) collects by scrolling the whole collection, to re-seed the SQL bookkeeping from
+        the index. ``indexed_at`` is that of the file's first stored chunk, as there."""
+        col = self._col
+        stats: dict[str, dict] = {}
+        with col.lock:
+            for row in col.live_rows():
+                payload = col.payload[row]
+                file_path = payload.get("file_path", "")
+                entry = stats.get(file_path)
+                if entry is None:
+                    entry = stats[file_path] = {"folder_path": payload.get("folder_path", ""),
+                                                "index_folder": payload.get("index_folder", ""),
+                                                "chunk_count": 0, "indexed_at": payload.get("indexed_at")}
+                entry["chunk_count"] += 1
+        return stats
+
 
 _vector_store: VectorStoreService | None = None
 
