@@ -1088,26 +1088,14 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny_kernel(const half_t* __re
   }
 }
 
-// sum of the K slices + the epilogue of the 256-tile kernel (same formulas), one float4 per thread
+// the epilogue of the 256-tile kernel (same formulas) for the float4 of raw sums v at row m, column n
 template <int EPI>
-__global__ void skinny_epilogue_kernel(const float* __restrict__ part, int slices, int M, int N, float unscale,
-                                       const float* __restrict__ bias, const float* __restrict__ R,
-                                       const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
-                                       const float* __restrict__ ln_b, float* __restrict__ C,
-                                       half_t* __restrict__ Ch) {
-  const int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t total4 = static_cast<int64_t>(M) * N / 4;
-  if (i4 >= total4) return;
-  const int64_t o = i4 * 4;
-  const int m = static_cast<int>(o / N), n = static_cast<int>(o % N);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < slices; ++s) {
-    const float4 p = *reinterpret_cast<const float4*>(part + static_cast<int64_t>(s) * M * N + o);
-    v.x += p.x;
-    v.y += p.y;
-    v.z += p.z;
-    v.w += p.w;
-  }
+__device__ __forceinline__ void skinny_apply(float4 v, int m, int n, int N, float unscale,
+                                             const float* __restrict__ bias, const float* __restrict__ R,
+                                             const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+                                             const float* __restrict__ ln_b, float* __restrict__ C,
+                                             half_t* __restrict__ Ch) {
+  const int64_t o = static_cast<int64_t>(m) * N + n;
   const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
   v.x = v.x * unscale + b4.x;
   v.y = v.y * unscale + b4.y;
@@ -1142,6 +1130,96 @@ __global__ void skinny_epilogue_kernel(const float* __restrict__ part, int slice
     }
   }
   *reinterpret_cast<float4*>(C + o) = v;
+}
+
+// sum of the K slices + epilogue, one float4 per thread (second launch of the split-K skinny GEMM)
+template <int EPI>
+__global__ void skinny_epilogue_kernel(const float* __restrict__ part, int slices, int M, int N, float unscale,
+                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                       const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+                                       const float* __restrict__ ln_b, float* __restrict__ C,
+                                       half_t* __restrict__ Ch) {
+  const int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t total4 = static_cast<int64_t>(M) * N / 4;
+  if (i4 >= total4) return;
+  const int64_t o = i4 * 4;
+  const int m = static_cast<int>(o / N), n = static_cast<int>(o % N);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < slices; ++s) {
+    const float4 p = *reinterpret_cast<const float4*>(part + static_cast<int64_t>(s) * M * N + o);
+    v.x += p.x;
+    v.y += p.y;
+    v.z += p.z;
+    v.w += p.w;
+  }
+  skinny_apply<EPI>(v, m, n, N, unscale, bias, R, ln_stat, ln_g, ln_b, C, Ch);
+}
+
+// One launch per skinny GEMM when K % 128 == 0 (every width of the supported models): a block owns 16
+// output columns and (up to) 64 activation rows; its four waves each take a QUARTER of K — so the weight
+// slab of the block (16 x K halfs) is streamed by four waves at once — and meet in LDS, where the
+// quarters are summed in wave order and the epilogue is applied. N/16 blocks (48-192 for the base
+// model) keep the weight stream wide without any cross-block reduction: a second launch costs ~4 us
+// here and a device-scope fence per block costs more, an LDS barrier costs nothing.
+template <int EPI, int UNR>
+__global__ __launch_bounds__(256) void gemm_f16_skinny1_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                               int M, int N, int K, float unscale,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ R,
+                                                               const float2* __restrict__ ln_stat,
+                                                               const float* __restrict__ ln_g,
+                                                               const float* __restrict__ ln_b, float* __restrict__ C,
+                                                               half_t* __restrict__ Ch) {
+  __shared__ float red[4][4][16][17];  // [wave][m block][output column][activation row (+1 pad)]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int m0 = blockIdx.y * kSkinnyM;
+  const int row = lane & 15, g = lane >> 4;
+  const int kq = K / 4, k0 = wave * kq;
+  const half_t* wp = W + static_cast<int64_t>(n0 + row) * K + k0 + 8 * g;
+  const half_t* ap[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) ap[mb] = A + static_cast<int64_t>(min(m0 + mb * 16 + row, M - 1)) * K + k0 + 8 * g;
+  f32x4 acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mblocks = (min(M - m0, kSkinnyM) + 15) / 16;
+  // UNR 32-deep steps at a time: all their loads are issued before the first MFMA (a dependent load per
+  // step would expose one memory latency per step, and a query's forward pass is nothing but latency)
+  for (int k = 0; k < kq; k += 32 * UNR) {
+    f16x8 wf[UNR], af[UNR][4];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      wf[u] = *reinterpret_cast<const f16x8*>(wp + k + 32 * u);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        if (mb < mblocks) af[u][mb] = *reinterpret_cast<const f16x8*>(ap[mb] + k + 32 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        if (mb < mblocks) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u], af[u][mb], acc[mb], 0, 0, 0);
+  }
+  // C layout: column (lane & 15) = activation row, rows 4g + r = output columns n0 + 4g + r
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][mb][4 * g + r][row] = acc[mb][r];
+  __syncthreads();
+  const int ml = threadIdx.x >> 2, n4 = (threadIdx.x & 3) * 4;  // 64 rows x 4 float4 of columns
+  const int m = m0 + ml;
+  if (m >= M) return;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float sum = red[0][ml >> 4][n4 + j][ml & 15];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += red[w][ml >> 4][n4 + j][ml & 15];  // fixed order
+    v[j] = sum;
+  }
+  skinny_apply<EPI>(make_float4(v[0], v[1], v[2], v[3]), m, n0 + n4, N, unscale, bias, R, ln_stat, ln_g, ln_b, C, Ch);
 }
 
 // weights: w * scale -> (hi, lo); scale is a power of two chosen from max|w| of the tensor
@@ -1203,7 +1281,33 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   hipStream_t s = e->stream;
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
-  if (passes == 1 && M <= 4 * kSkinnyM && skinny_slice(K) > 0 && N % 64 == 0) {
+  const int quarter_steps = K % 128 == 0 ? K / 128 : 0;  // 32-deep MFMA steps per wave of the one-launch skinny kernel
+  if (passes == 1 && M <= 4 * kSkinnyM && quarter_steps > 0 && (quarter_steps % 4 == 0 || quarter_steps % 3 == 0) &&
+      N % 16 == 0) {
+    const dim3 sg(static_cast<unsigned>(N / 16), static_cast<unsigned>((M + kSkinnyM - 1) / kSkinnyM));
+    const bool by4 = quarter_steps % 4 == 0;
+#define VR_SKINNY1(E)                                                                                                  \
+  do {                                                                                                                 \
+    if (by4)                                                                                                           \
+      hipLaunchKernelGGL((gemm_f16_skinny1_kernel<E, 4>), sg, dim3(256), 0, s, Ah, Wh, M, N, K, unscale, bias, R, ln_stat, \
+                         ln_g, ln_b, C, Ch);                                                                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gemm_f16_skinny1_kernel<E, 3>), sg, dim3(256), 0, s, Ah, Wh, M, N, K, unscale, bias, R, ln_stat, \
+                         ln_g, ln_b, C, Ch);                                                                          \
+  } while (0)
+    switch (epi) {
+      case EPI_BIAS: VR_SKINNY1(EPI_BIAS); break;
+      case EPI_BIAS_GELU: VR_SKINNY1(EPI_BIAS_GELU); break;
+      case EPI_BIAS_F16: VR_SKINNY1(EPI_BIAS_F16); break;
+      case EPI_BIAS_RESIDUAL_LN: VR_SKINNY1(EPI_BIAS_RESIDUAL_LN); break;
+      default: VR_SKINNY1(EPI_BIAS_RESIDUAL); break;
+    }
+#undef VR_SKINNY1
+    prof_end(e);
+    VR_HIP(hipGetLastError());
+    return 0;
+  }
+  if (passes == 1 && M <= 4 * kSkinnyM && skinny_slice(K) > 0 && N % 64 == 0) {  // K % 128 != 0: split-K, two launches
     Encoder* enc = static_cast<Encoder*>(e->encoder);
     const int kslice = skinny_slice(K), slices = K / kslice;
     {
