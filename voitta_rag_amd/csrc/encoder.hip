@@ -1156,13 +1156,13 @@ __global__ void skinny_epilogue_kernel(const float* __restrict__ part, int slice
 }
 
 // One launch per skinny GEMM when K % 128 == 0 (every width of the supported models): a block owns 16
-// output columns and (up to) 64 activation rows; its four waves each take a QUARTER of K — so the weight
-// slab of the block (16 x K halfs) is streamed by four waves at once — and meet in LDS, where the
-// quarters are summed in wave order and the epilogue is applied. N/16 blocks (48-192 for the base
+// output columns and (up to) 64 activation rows; its NW = 8 (4 when K % 256 != 0) waves each take 1/NW of K
+// — so the weight slab of the block (16 x K halfs) is streamed by all of them at once, in 1-3 memory round
+// trips per wave — and meet in LDS, where the shares are summed in wave order and the epilogue is applied. N/16 blocks (48-192 for the base
 // model) keep the weight stream wide without any cross-block reduction: a second launch costs ~4 us
 // here and a device-scope fence per block costs more, an LDS barrier costs nothing.
-template <int EPI, int UNR>
-__global__ __launch_bounds__(256) void gemm_f16_skinny1_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+template <int EPI, int UNR, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_f16_skinny1_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                                int M, int N, int K, float unscale,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ R,
@@ -1170,13 +1170,13 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny1_kernel(const half_t* __r
                                                                const float* __restrict__ ln_g,
                                                                const float* __restrict__ ln_b, float* __restrict__ C,
                                                                half_t* __restrict__ Ch) {
-  __shared__ float red[4][4][16][17];  // [wave][m block][output column][activation row (+1 pad)]
+  __shared__ float red[NW][4][16][17];  // [wave][m block][output column][activation row (+1 pad)]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 16;
   const int m0 = blockIdx.y * kSkinnyM;
   const int row = lane & 15, g = lane >> 4;
-  const int kq = K / 4, k0 = wave * kq;
+  const int kq = K / NW, k0 = wave * kq;  // this wave's share of K
   const half_t* wp = W + static_cast<int64_t>(n0 + row) * K + k0 + 8 * g;
   const half_t* ap[4];
 #pragma unroll
@@ -1208,6 +1208,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny1_kernel(const half_t* __r
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][mb][4 * g + r][row] = acc[mb][r];
   __syncthreads();
+  if (threadIdx.x >= 256) return;
   const int ml = threadIdx.x >> 2, n4 = (threadIdx.x & 3) * 4;  // 64 rows x 4 float4 of columns
   const int m = m0 + ml;
   if (m >= M) return;
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny1_kernel(const half_t* __r
   for (int j = 0; j < 4; ++j) {
     float sum = red[0][ml >> 4][n4 + j][ml & 15];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) sum += red[w][ml >> 4][n4 + j][ml & 15];  // fixed order
+    for (int w = 1; w < NW; ++w) sum += red[w][ml >> 4][n4 + j][ml & 15];  // fixed order
     v[j] = sum;
   }
   skinny_apply<EPI>(make_float4(v[0], v[1], v[2], v[3]), m, n0 + n4, N, unscale, bias, R, ln_stat, ln_g, ln_b, C, Ch);
@@ -1281,19 +1282,27 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
   hipStream_t s = e->stream;
   static const int force_tile = getenv("VR_GEMM_TILE") ? atoi(getenv("VR_GEMM_TILE")) : 0;  // 128: A/B runs
   prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
-  const int quarter_steps = K % 128 == 0 ? K / 128 : 0;  // 32-deep MFMA steps per wave of the one-launch skinny kernel
-  if (passes == 1 && M <= 4 * kSkinnyM && quarter_steps > 0 && (quarter_steps % 4 == 0 || quarter_steps % 3 == 0) &&
-      N % 16 == 0) {
+  // one-launch skinny kernel: 8 waves per block when an eighth of K is whole 32-deep MFMA steps, else 4;
+  // UNR = steps whose loads are issued together (the largest of 6, 4, 3 dividing the wave's step count)
+  const int sk_waves = K % 256 == 0 ? 8 : K % 128 == 0 ? 4 : 0;
+  const int sk_steps = sk_waves ? K / (32 * sk_waves) : 0;
+  const int sk_unr = sk_steps == 0 ? 0 : sk_steps % 6 == 0 ? 6 : sk_steps % 4 == 0 ? 4 : sk_steps % 3 == 0 ? 3 : 0;
+  if (passes == 1 && M <= 4 * kSkinnyM && sk_unr > 0 && N % 16 == 0) {
     const dim3 sg(static_cast<unsigned>(N / 16), static_cast<unsigned>((M + kSkinnyM - 1) / kSkinnyM));
-    const bool by4 = quarter_steps % 4 == 0;
-#define VR_SKINNY1(E)                                                                                                  \
-  do {                                                                                                                 \
-    if (by4)                                                                                                           \
-      hipLaunchKernelGGL((gemm_f16_skinny1_kernel<E, 4>), sg, dim3(256), 0, s, Ah, Wh, M, N, K, unscale, bias, R, ln_stat, \
-                         ln_g, ln_b, C, Ch);                                                                          \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gemm_f16_skinny1_kernel<E, 3>), sg, dim3(256), 0, s, Ah, Wh, M, N, K, unscale, bias, R, ln_stat, \
-                         ln_g, ln_b, C, Ch);                                                                          \
+#define VR_SKINNY1_LAUNCH(E, U, W)                                                                                    \
+  hipLaunchKernelGGL((gemm_f16_skinny1_kernel<E, U, W>), sg, dim3(W * 64), 0, s, Ah, Wh, M, N, K, unscale, bias, R,  \
+                     ln_stat, ln_g, ln_b, C, Ch)
+#define VR_SKINNY1(E)                                                  \
+  do {                                                                 \
+    if (sk_waves == 8) {                                               \
+      if (sk_unr == 6) VR_SKINNY1_LAUNCH(E, 6, 8);                     \
+      else if (sk_unr == 4) VR_SKINNY1_LAUNCH(E, 4, 8);                \
+      else VR_SKINNY1_LAUNCH(E, 3, 8);                                 \
+    } else {                                                           \
+      if (sk_unr == 6) VR_SKINNY1_LAUNCH(E, 6, 4);                     \
+      else if (sk_unr == 4) VR_SKINNY1_LAUNCH(E, 4, 4);                \
+      else VR_SKINNY1_LAUNCH(E, 3, 4);                                 \
+    }                                                                  \
   } while (0)
     switch (epi) {
       case EPI_BIAS: VR_SKINNY1(EPI_BIAS); break;
@@ -1303,6 +1312,7 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
       default: VR_SKINNY1(EPI_BIAS_RESIDUAL); break;
     }
 #undef VR_SKINNY1
+#undef VR_SKINNY1_LAUNCH
     prof_end(e);
     VR_HIP(hipGetLastError());
     return 0;
