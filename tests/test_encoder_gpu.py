@@ -168,3 +168,29 @@ def test_small_batches_replayed_as_graphs_are_bit_identical(gpu):
     assert np.array_equal(enc.encode(e, a_ids, a_off), first["a"])
     e.close()
     fresh.close()
+
+
+@pytest.mark.parametrize("name,layers,lens", [
+    ("bge-base-en-v1.5", 3, [12]),           # CLS pooling: last layer runs its [CLS]-only tail
+    ("bge-base-en-v1.5", 12, [7]),
+    ("e5-base-v2", 3, [16]),                 # mean pooling: the very last LayerNorm stays a launch of its own
+    ("e5-base-v2", 2, [5, 4, 3, 2, 2]),      # five short sequences, 16 tokens
+    ("all-MiniLM-L6-v2", 6, [9]),
+    ("bge-large-en-v1.5", 3, [11]),
+])
+def test_single_query_path_folds_layernorm_into_the_projections(gpu, name, layers, lens):
+    """<= 16 tokens in f16 mode: the LayerNorm launches are folded into the Q/K/V and FFN-up projections
+    (gemm_f16_skinny_ln_kernel). Same tolerance as every other f16 path against the f64 oracle, and the
+    embeddings agree with those of the same sequences encoded inside a larger batch (unfolded path) to 1e-6."""
+    base, pooling = obert.SHAPES[name]
+    shape = obert.BertShape(layers, base.hidden, base.heads, base.intermediate, vocab=1000, max_pos=base.max_pos)
+    w = obert.random_weights(shape, 17)
+    rng = np.random.default_rng(8)
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+    got = _encode(shape, pooling, w, seqs, "f16")
+    want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
+    _check(got, want, f"{name} folded LN, {sum(lens)} tokens", "f16")
+    padded = seqs + [rng.integers(0, shape.vocab, size=40).astype(np.int32)]
+    other = _encode(shape, pooling, w, padded, "f16")[: len(seqs)]
+    cos = (got * other).sum(1)
+    assert np.max(np.abs(1.0 - cos)) < 1e-6

@@ -1271,6 +1271,127 @@ static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const
 #undef VR_LAUNCH_256
 }
 
+// The skinny GEMM of a handful of tokens (M <= 16) with the LayerNorm IN FRONT of it folded in: the
+// activation operand is built from the pre-LayerNorm f32 rows instead of being read as f16 rows that a
+// LayerNorm launch wrote a few microseconds earlier. Every block recomputes the (mean, 1/sigma) of the
+// <= 16 rows (two passes over values it holds in registers, cross-wave sums in LDS in wave order, so every
+// block gets the same bits), normalises its waves' shares of the columns and feeds the MFMA; block 0 also
+// stores the statistics, which the residual epilogue of the NEXT projection needs (ln_apply re-derives
+// the LayerNorm output from the pre-LN row). K = hidden size: each wave holds STEPS * 8 values per row.
+// Two launches fewer per layer for a single query (7 -> 5): its forward pass is launch latency, not work.
+template <int EPI, int STEPS, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_f16_skinny_ln_kernel(
+    const float* __restrict__ pre, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
+    float2* __restrict__ stat_out, const half_t* __restrict__ W, int M, int N, int K, float unscale,
+    const float* __restrict__ bias, half_t* __restrict__ Ch) {
+  __shared__ float red[NW][16][17];  // [wave][output column][activation row (+1 pad)]
+  __shared__ float part[2][NW][16];  // row sums per wave: [pass][wave][row]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int row = lane & 15, g = lane >> 4;
+  const int kq = K / NW, k0 = wave * kq;
+  const float* xp = pre + static_cast<int64_t>(min(row, M - 1)) * K + k0 + 8 * g;
+  const half_t* wp = W + static_cast<int64_t>(n0 + row) * K + k0 + 8 * g;
+  float x[STEPS][8];
+  f16x8 wf[STEPS];
+  float sum = 0.0f;
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {
+    wf[u] = *reinterpret_cast<const f16x8*>(wp + 32 * u);
+    const float4 a = *reinterpret_cast<const float4*>(xp + 32 * u), c = *reinterpret_cast<const float4*>(xp + 32 * u + 4);
+    x[u][0] = a.x, x[u][1] = a.y, x[u][2] = a.z, x[u][3] = a.w, x[u][4] = c.x, x[u][5] = c.y, x[u][6] = c.z, x[u][7] = c.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += x[u][j];
+  }
+  // a row's values of this wave sit in the four lanes row, row + 16, row + 32, row + 48
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  if (g == 0) part[0][wave][row] = sum;
+  __syncthreads();
+  float total = part[0][0][row];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) total += part[0][w][row];
+  const float mean = total / static_cast<float>(K);
+  float sq = 0.0f;
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = x[u][j] - mean;
+      sq += d * d;
+    }
+  sq += __shfl_xor(sq, 16);
+  sq += __shfl_xor(sq, 32);
+  if (g == 0) part[1][wave][row] = sq;
+  __syncthreads();
+  float total_sq = part[1][0][row];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) total_sq += part[1][w][row];
+  const float inv = 1.0f / sqrtf(total_sq / static_cast<float>(K) + eps);
+  if (blockIdx.x == 0 && wave == 0 && g == 0 && row < M) stat_out[row] = make_float2(mean, inv);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {
+    const float4 g0 = *reinterpret_cast<const float4*>(ln_g + k0 + 8 * g + 32 * u), g1 = *reinterpret_cast<const float4*>(ln_g + k0 + 8 * g + 32 * u + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(ln_b + k0 + 8 * g + 32 * u), b1 = *reinterpret_cast<const float4*>(ln_b + k0 + 8 * g + 32 * u + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    f16x8 af;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      half_t h, l;
+      split_f16(ln_apply(x[u][j], mean, inv, gg[j], bb[j]), h, l);  // as layernorm_f16_kernel rounds its output
+      af[j] = h;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u], af, acc, 0, 0, 0);
+  }
+  // C layout: column (lane & 15) = activation row, rows 4g + r = output columns n0 + 4g + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][4 * g + r][row] = acc[r];
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int m = threadIdx.x >> 2, n4 = (threadIdx.x & 3) * 4;  // 16 rows x 4 float4 of columns
+  if (m >= M) return;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = red[0][n4 + j][m];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][n4 + j][m];  // fixed order
+    v[j] = t;
+  }
+  skinny_apply<EPI>(make_float4(v[0], v[1], v[2], v[3]), m, n0 + n4, N, unscale, bias, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, Ch);
+}
+
+// K = hidden size H: 8 waves x 3 steps (768), 8 x 4 (1024), 4 x 3 (384); anything else keeps the LayerNorm launch
+static bool skinny_ln_supported(int M, int N, int K) { return M <= 16 && N % 16 == 0 && (K == 768 || K == 1024 || K == 384); }
+
+static int launch_skinny_ln(vr_engine* e, int epi, const float* pre, const float* ln_g, const float* ln_b, float eps,
+                            float2* stat_out, const half_t* W, float unscale, const float* bias, half_t* Ch, int M,
+                            int N, int K) {
+  hipStream_t s = e->stream;
+  prof_begin(e, VR_PROF_GEMM, 2.0 * M * static_cast<double>(N) * K);
+  const dim3 grid(static_cast<unsigned>(N / 16));
+#define VR_SKINNY_LN(E, ST, NWV)                                                                                   \
+  hipLaunchKernelGGL((gemm_f16_skinny_ln_kernel<E, ST, NWV>), grid, dim3(NWV * 64), 0, s, pre, ln_g, ln_b, eps,    \
+                     stat_out, W, M, N, K, unscale, bias, Ch)
+  if (epi == EPI_BIAS_GELU) {
+    if (K == 768) VR_SKINNY_LN(EPI_BIAS_GELU, 3, 8);
+    else if (K == 1024) VR_SKINNY_LN(EPI_BIAS_GELU, 4, 8);
+    else VR_SKINNY_LN(EPI_BIAS_GELU, 3, 4);
+  } else {
+    if (K == 768) VR_SKINNY_LN(EPI_BIAS_F16, 3, 8);
+    else if (K == 1024) VR_SKINNY_LN(EPI_BIAS_F16, 4, 8);
+    else VR_SKINNY_LN(EPI_BIAS_F16, 3, 4);
+  }
+#undef VR_SKINNY_LN
+  prof_end(e);
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
 // passes = 3: operands are interleaved (hi, lo) rows (Al = Ah + 8, Wl = Wh + 8); passes = 1: plain f16
 // rows, Al / Wl / Cl unused.
 static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half_t* Al, const half_t* Wh,
@@ -1838,6 +1959,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   Hidden cur{enc->x, stat_b, enc->lng, enc->lnb};
   const float* final_x = enc->x;  // the f32 rows pooling reads
   const bool lnfuse = plain && !enc->layers.empty();  // (a model without layers pools the embedding LayerNorm's output)
+  // a handful of tokens (one query): the two LayerNorm launches of a layer are folded into the projections
+  // that consume them (gemm_f16_skinny_ln_kernel); VR_ENCODE_FOLD_LN=0 keeps them apart
+  static const bool fold_ln_enabled = !(getenv("VR_ENCODE_FOLD_LN") && atoi(getenv("VR_ENCODE_FOLD_LN")) == 0);
+  const bool fold_ln = lnfuse && fold_ln_enabled && skinny_ln_supported(T, 3 * H, H) && I % 16 == 0;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
                      lnfuse ? nullptr : enc->x, xh, xl, lnfuse ? enc->x : nullptr, lnfuse ? stat_b : nullptr);
@@ -1861,7 +1986,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   for (size_t li = 0; li < enc->layers.size(); ++li) {
     const LayerWeights& w = enc->layers[li];
     const bool tail = cls_tail && li + 1 == enc->layers.size();
-    if (plain)  // Q, K, V as plain f16 rows for attention_f16_kernel
+    if (plain && fold_ln && li > 0)  // the previous layer's closing LayerNorm runs inside this projection
+      VR_TRY(launch_skinny_ln(e, EPI_BIAS_F16, cur.pre, cur.g, cur.b, d.eps, const_cast<float2*>(cur.stat), w.s_qkv.hi,
+                              w.s_qkv.unscale, w.bqkv, reinterpret_cast<half_t*>(enc->qkv), T, 3 * H, H));
+    else if (plain)  // Q, K, V as plain f16 rows for attention_f16_kernel
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_F16, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
                                nullptr, reinterpret_cast<half_t*>(enc->qkv), nullptr, T, 3 * H, H, passes));
     else if (split)
@@ -1928,7 +2056,9 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       float2* s1 = cur.stat == stat_b ? stat_a : stat_b;
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre, t1,
                                nullptr, nullptr, T, H, H, 1, cur.stat, cur.g, cur.b));
-      if (H % 256 == 0)
+      if (fold_ln)
+        ;  // the attention-output LayerNorm runs inside the FFN-up projection below
+      else if (H % 256 == 0)
         hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
                            static_cast<float*>(nullptr), xh, s1);
       else
@@ -1937,13 +2067,18 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       const Hidden mid{t1, s1, w.ln1g, w.ln1b};
       float* t2 = const_cast<float*>(cur.pre);  // its last reader (the epilogue above) is done
       float2* s2 = const_cast<float2*>(cur.stat);
+      if (fold_ln)
+        VR_TRY(launch_skinny_ln(e, EPI_BIAS_GELU, t1, w.ln1g, w.ln1b, d.eps, s1, w.s_1.hi, w.s_1.unscale, w.b1, fh, T, I, H));
+      else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, nullptr, w.s_1.hi, nullptr, w.s_1.unscale, w.b1, nullptr, nullptr, fh,
                                nullptr, T, I, H, 1));
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre, t2,
                                nullptr, nullptr, T, H, I, 1, mid.stat, mid.g, mid.b));
       // the last LayerNorm of the network also stores its f32 rows (into the free buffer): pooling reads them
       const bool last = li + 1 == enc->layers.size();
-      if (H % 256 == 0)
+      if (fold_ln && !last)
+        ;  // this layer's closing LayerNorm runs inside the next layer's Q/K/V projection
+      else if (H % 256 == 0)
         hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
                            last ? t1 : static_cast<float*>(nullptr), xh, s2);
       else
