@@ -194,3 +194,24 @@ def test_single_query_path_folds_layernorm_into_the_projections(gpu, name, layer
     other = _encode(shape, pooling, w, padded, "f16")[: len(seqs)]
     cos = (got * other).sum(1)
     assert np.max(np.abs(1.0 - cos)) < 1e-6
+
+
+@pytest.mark.parametrize("name,layers,lens", [
+    ("bge-base-en-v1.5", 3, [120, 97, 64, 33, 128, 101]),   # CLS: last layer runs its [CLS]-only tail
+    ("e5-base-v2", 3, [128, 90, 77, 110, 45]),              # mean pooling: the very last LayerNorm stays a kernel
+    ("bge-large-en-v1.5", 2, [100, 128, 60, 75]),
+    ("bge-base-en-v1.5", 12, [128, 128, 64]),               # full depth through the folded path
+])
+def test_large_batches_fold_layernorm_into_the_gemms(gpu, name, layers, lens):
+    """More than 256 tokens in f16 mode: no LayerNorm pass between the GEMMs — the producing epilogue stores
+    f16 pre-LN rows and partial row sums, the consuming GEMM carries the LayerNorm gain in its weights and
+    applies (mean, 1/sigma) in its epilogue (EPI_FOLD_*). Same bar against the f64 oracle as every f16 path."""
+    base, pooling = obert.SHAPES[name]
+    shape = obert.BertShape(layers, base.hidden, base.heads, base.intermediate, vocab=1000, max_pos=base.max_pos)
+    w = obert.random_weights(shape, 23)
+    rng = np.random.default_rng(9)
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+    assert sum(lens) > 256
+    got = _encode(shape, pooling, w, seqs, "f16")
+    want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
+    _check(got, want, f"{name} L{layers} folded GEMM LN, {sum(lens)} tokens", "f16")

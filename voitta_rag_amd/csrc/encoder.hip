@@ -40,6 +40,10 @@ struct SplitWeight {  // f16x3 mode: w * 2^s as (hi, lo) f16, [out][in]; unscale
 struct LayerWeights {
   float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
   SplitWeight s_qkv, s_o, s_1, s_2;
+  // f16 mode, LayerNorm folded into the consuming GEMM (see EPI_FOLD_*): weights scaled by the LayerNorm
+  // gain in front of them, their column sums and the bias with the LayerNorm shift pushed through
+  SplitWeight s_qkv_f{}, s_1_f{};  // s_qkv_f: layers >= 1 only (layer 0 reads the embedding LayerNorm's output)
+  float *cs_qkv = nullptr, *c_qkv = nullptr, *cs_1 = nullptr, *c_1 = nullptr;
 };
 
 struct Encoder {
@@ -52,6 +56,7 @@ struct Encoder {
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
   float* xs = nullptr;  // f16x3 / f16 mode: the hidden state as GEMM input ((hi, lo) or plain f16 rows)
   float* lnstat = nullptr;  // f16 mode: two arrays of per-row (mean, 1/sigma), see forward_chunk
+  float* lnpart = nullptr;  // f16 mode: per (row, 64 columns) partial (sum, sum of squares) of the folded LayerNorms
   DevArray<int32_t> ids, cu;
   DevArray<float> out;
   DevArray<float> skinny_ws;  // K-slice partial sums of gemm_f16_skinny_kernel
@@ -418,7 +423,13 @@ constexpr int LDT = BK + 4;  // padded LDS row (floats); rows stay 16-byte align
 
 // F16: plain f16 output; RESIDUAL_LN: the residual is LayerNorm(R) re-derived from the pre-LN rows R and
 // their (mean, 1/sigma) — both in the 256-tile kernel only
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3, EPI_BIAS_RESIDUAL_LN = 4 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3, EPI_BIAS_RESIDUAL_LN = 4,
+       // LayerNorm folded into the GEMMs of the large-batch f16 path (forward_chunk, `fold_big`):
+       //   LN(x) W^T = inv (x (g o W)^T - mean colsum(g o W)) + W b  — the consumer reads f16 PRE-LN rows and its
+       //   epilogue applies the row statistics (FOLD_*: bias = c, ln_g = colsum, ln_stat = (mean, 1/sigma));
+       //   the producer (RESIDUAL_LN_STATS) also stores its output rows as f16 and per-(row, 64 columns)
+       //   partial (sum, sum of squares), from which ln_finalize_kernel makes the statistics.
+       EPI_FOLD_F16 = 5, EPI_FOLD_GELU = 6, EPI_BIAS_RESIDUAL_LN_STATS = 7 };
 
 // Linear tile id -> (row panel, column panel), row panels taken kGroupM at a time with the column
 // index slow inside a group. The ~32 blocks an XCD runs together then cover ~8 row panels x ~4
@@ -940,12 +951,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
   const int gcol = bn + wn * 64 + c4;
   const bool col_ok = gcol < N;  // N % 4 == 0: a lane's four columns are in or out together
   const float4 b4 = *reinterpret_cast<const float4*>(bias + (col_ok ? gcol : 0));
-  constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN;
-  float4 lg4 = make_float4(0.f, 0.f, 0.f, 0.f), lb4 = lg4;  // LayerNorm weight / bias of this lane's columns
-  if (EPI == EPI_BIAS_RESIDUAL_LN) {
-    lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
-    lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
-  }
+  constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
+  constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS;
+  constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
+  constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
+  // LayerNorm weight / bias of this lane's columns (residual re-derivation), or, folded consumers: the
+  // column sums of the LayerNorm-scaled weight matrix
+  float4 lg4 = make_float4(0.f, 0.f, 0.f, 0.f), lb4 = lg4;
+  if (kResidLN || kFold) lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
+  if (kResidLN) lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
   // The residual rows of a 16-row piece are requested one piece AHEAD, four loads at once (read one
   // by one inside the store loop they cost an exposed HBM latency each), with their (mean, 1/sigma)
   // when the residual is a LayerNorm output.
@@ -955,15 +969,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int64_t rr = min(bm + wm * 128 + 16 * pc + (lane >> 4) + 4 * it, M - 1);
-      r[it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
-      if (EPI == EPI_BIAS_RESIDUAL_LN) st[it] = ln_stat[rr];
+      if (kResidual) r[it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
+      if (kResidLN || kFold) st[it] = ln_stat[rr];
     }
   };
-  if (kResidual) fetch_residual(0, r4[0], st4[0]);
+  if (kResidual || kFold) fetch_residual(0, r4[0], st4[0]);
 #pragma unroll
   for (int pc = 0; pc < 8; ++pc) {  // piece pc = rows 16 pc .. 16 pc + 15 of the wave's 128 = MFMA tile row pc
     const int row0 = bm + wm * 128 + 16 * pc + (lane >> 4);  // + 4 * it
-    if (kResidual && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
+    if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -975,13 +989,22 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
       const int lr = it * 4 + (lane >> 4);
       const int grow = row0 + 4 * it;
       float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
-      if (grow >= M || !col_ok) return;
-      v.x = v.x * unscale + b4.x;
-      v.y = v.y * unscale + b4.y;
-      v.z = v.z * unscale + b4.z;
-      v.w = v.w * unscale + b4.w;
+      const bool ok = grow < M && col_ok;
+      if (!kStats && !ok) return;  // (the statistics variant keeps every lane for its row sums)
+      if (kFold) {  // inv (acc unscale - mean colsum) + c
+        const float2 st = st4[pc & 1][it];
+        v.x = fmaf(fmaf(v.x, unscale, -(st.x * lg4.x)), st.y, b4.x);
+        v.y = fmaf(fmaf(v.y, unscale, -(st.x * lg4.y)), st.y, b4.y);
+        v.z = fmaf(fmaf(v.z, unscale, -(st.x * lg4.z)), st.y, b4.z);
+        v.w = fmaf(fmaf(v.w, unscale, -(st.x * lg4.w)), st.y, b4.w);
+      } else {
+        v.x = v.x * unscale + b4.x;
+        v.y = v.y * unscale + b4.y;
+        v.z = v.z * unscale + b4.z;
+        v.w = v.w * unscale + b4.w;
+      }
       const int64_t o = static_cast<int64_t>(grow) * N + gcol;
-      if (EPI == EPI_BIAS_GELU) {
+      if (EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU) {
         const f32x2 g01 = PASSES == 1 ? gelu_poly2(f32x2{v.x, v.y}) : gelu_fast2(f32x2{v.x, v.y});
         const f32x2 g23 = PASSES == 1 ? gelu_poly2(f32x2{v.z, v.w}) : gelu_fast2(f32x2{v.z, v.w});
         float g[4] = {g01.x, g01.y, g23.x, g23.y};
@@ -995,7 +1018,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
         } else {
           *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);  // plain f16 rows
         }
-      } else if (EPI == EPI_BIAS_F16) {  // Q, K, V for the f16 attention kernel
+      } else if (EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16) {  // Q, K, V for the f16 attention kernel
         half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
                        static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
                        static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
@@ -1008,14 +1031,38 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
           v.z += r4[pc & 1][it].z;
           v.w += r4[pc & 1][it].w;
         }
-        if (EPI == EPI_BIAS_RESIDUAL_LN) {  // residual = LayerNorm(R row), exactly as the LN kernel would have stored it
+        if (kResidLN) {  // residual = LayerNorm(R row), exactly as the LN kernel would have stored it
           const float2 st = st4[pc & 1][it];
           v.x += ln_apply(r4[pc & 1][it].x, st.x, st.y, lg4.x, lb4.x);
           v.y += ln_apply(r4[pc & 1][it].y, st.x, st.y, lg4.y, lb4.y);
           v.z += ln_apply(r4[pc & 1][it].z, st.x, st.y, lg4.z, lb4.z);
           v.w += ln_apply(r4[pc & 1][it].w, st.x, st.y, lg4.w, lb4.w);
         }
-        *reinterpret_cast<float4*>(C + o) = v;
+        if (!kStats) {
+          *reinterpret_cast<float4*>(C + o) = v;
+        } else {
+          // the pre-LayerNorm row also goes out as f16 (the next projection's operand), and this wave's 64
+          // columns of it contribute a (sum, sum of squares) to the row's statistics
+          float s1 = 0.0f, s2 = 0.0f;
+          if (ok) {
+            *reinterpret_cast<float4*>(C + o) = v;
+            half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
+                           static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
+                           static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
+                           static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
+            *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+            s1 = (v.x + v.y) + (v.z + v.w);
+            s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) {  // the 16 lanes that share the row
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+          }
+          const int seg = (bn + wn * 64) >> 6;
+          if ((lane & 15) == 0 && grow < M && seg < (N >> 6))
+            reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(s1, s2);
+        }
       }
     };
 #pragma unroll
@@ -1266,6 +1313,9 @@ static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const
     case EPI_BIAS_GELU: VR_LAUNCH_256(EPI_BIAS_GELU); break;
     case EPI_BIAS_F16: VR_LAUNCH_256(EPI_BIAS_F16); break;
     case EPI_BIAS_RESIDUAL_LN: VR_LAUNCH_256(EPI_BIAS_RESIDUAL_LN); break;
+    case EPI_FOLD_F16: if constexpr (PASSES == 1) VR_LAUNCH_256(EPI_FOLD_F16); break;
+    case EPI_FOLD_GELU: if constexpr (PASSES == 1) VR_LAUNCH_256(EPI_FOLD_GELU); break;
+    case EPI_BIAS_RESIDUAL_LN_STATS: if constexpr (PASSES == 1) VR_LAUNCH_256(EPI_BIAS_RESIDUAL_LN_STATS); break;
     default: VR_LAUNCH_256(EPI_BIAS_RESIDUAL); break;
   }
 #undef VR_LAUNCH_256
@@ -1796,6 +1846,54 @@ static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_
 }
 
 // w (device, n floats) -> scaled (hi, lo) f16 pair; scale = 2^s puts max|w| into [1024, 2048)
+// (mean, 1/sigma) of every row from the per-64-column partial sums of EPI_BIAS_RESIDUAL_LN_STATS
+__global__ void ln_finalize_kernel(const float2* __restrict__ part, int T, int segs, int H, float eps,
+                                   float2* __restrict__ stat) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int i = 0; i < segs; ++i) {  // fixed order
+    const float2 p = part[static_cast<int64_t>(t) * segs + i];
+    s1 += p.x;
+    s2 += p.y;
+  }
+  const float mean = s1 / static_cast<float>(H);
+  const float var = fmaxf(s2 / static_cast<float>(H) - mean * mean, 0.0f);
+  stat[t] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+// out[n][k] = w[n][k] * g[k]
+__global__ void scale_cols_kernel(const float* __restrict__ w, const float* __restrict__ g, int64_t n, int K,
+                                  float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = w[i] * g[i % K];
+}
+
+// one wave per output column n: colsum[n] = unscale * sum_k f16 weight[n][k] (the weights the MFMA really
+// multiplies by), c[n] = bias[n] + sum_k w[n][k] b[k] (f32 weights, f64 accumulation)
+__global__ __launch_bounds__(256) void fold_vectors_kernel(const half_t* __restrict__ wq, float unscale,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ bias, int N, int K,
+                                                           float* __restrict__ colsum, float* __restrict__ c) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  double sq = 0.0, sc = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    sq += static_cast<double>(static_cast<float>(wq[static_cast<int64_t>(n) * K + k]));
+    sc += static_cast<double>(w[static_cast<int64_t>(n) * K + k]) * static_cast<double>(b[k]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sq += __shfl_xor(sq, off);
+    sc += __shfl_xor(sc, off);
+  }
+  if (lane == 0) {
+    colsum[n] = static_cast<float>(sq * static_cast<double>(unscale));
+    c[n] = static_cast<float>(static_cast<double>(bias[n]) + sc);
+  }
+}
+
 static int make_split(vr_engine* e, Encoder* enc, const float* w_dev, size_t n, int K, bool plain, SplitWeight* out) {
   float* scratch = nullptr;
   VR_TRY(dev_alloc_copy(e, enc, nullptr, 1, 0, &scratch));
@@ -1891,6 +1989,30 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
       VR_TRY(make_split(e, enc, lw.wo, HH, H, plain, &lw.s_o));
       VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, H, plain, &lw.s_1));
       VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, I, plain, &lw.s_2));
+      if (plain && H % 256 == 0) {  // operands of the folded-LayerNorm GEMMs
+        auto fold = [&](const float* w_dev, int N, const float* g, const float* b, const float* bias, SplitWeight* sw,
+                        float** colsum, float** c) -> int {
+          const size_t n = static_cast<size_t>(N) * H;
+          float* scaled = nullptr;
+          VR_HIP(hipMalloc(reinterpret_cast<void**>(&scaled), n * sizeof(float)));
+          hipLaunchKernelGGL(scale_cols_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream, w_dev,
+                             g, static_cast<int64_t>(n), H, scaled);
+          int rc = make_split(e, enc, scaled, n, H, true, sw);
+          if (rc == 0) rc = dev_alloc_copy(e, enc, nullptr, N, 0, colsum);
+          if (rc == 0) rc = dev_alloc_copy(e, enc, nullptr, N, 0, c);
+          if (rc == 0)
+            hipLaunchKernelGGL(fold_vectors_kernel, dim3(static_cast<unsigned>((N + 3) / 4)), dim3(256), 0, e->stream, sw->hi,
+                               sw->unscale, w_dev, b, bias, N, H, *colsum, *c);
+          (void)hipStreamSynchronize(e->stream);
+          (void)hipFree(scaled);
+          return rc;
+        };
+        VR_TRY(fold(lw.w1, I, lw.ln1g, lw.ln1b, lw.b1, &lw.s_1_f, &lw.cs_1, &lw.c_1));
+        if (!enc->layers.empty()) {
+          const LayerWeights& prev = enc->layers.back();
+          VR_TRY(fold(lw.wqkv, 3 * H, prev.ln2g, prev.ln2b, lw.bqkv, &lw.s_qkv_f, &lw.cs_qkv, &lw.c_qkv));
+        }
+      }
     }
     enc->layers.push_back(lw);
   }
@@ -1902,7 +2024,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   if (tokens <= enc->ws_tokens) return 0;
   VR_HIP(hipStreamSynchronize(e->stream));
   invalidate_graphs(enc);
-  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs, &enc->lnstat}) {
+  for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs, &enc->lnstat, &enc->lnpart}) {
     if (*p) {
       enc->owned.erase(std::remove(enc->owned.begin(), enc->owned.end(), *p), enc->owned.end());
       (void)hipFree(*p);
@@ -1918,6 +2040,7 @@ static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   VR_TRY(dev_alloc_copy(e, enc, nullptr, T * I, 0, &enc->ffn));
   if (enc->d.precision != VR_PRECISION_F32) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * H, 0, &enc->xs));
   if (enc->d.precision == VR_PRECISION_F16) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * 4, 0, &enc->lnstat));
+  if (enc->d.precision == VR_PRECISION_F16) VR_TRY(dev_alloc_copy(e, enc, nullptr, T * ((H + 63) / 64) * 2, 0, &enc->lnpart));
   enc->ws_tokens = tokens;
   return 0;
 }
@@ -1963,6 +2086,15 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   // that consume them (gemm_f16_skinny_ln_kernel); VR_ENCODE_FOLD_LN=0 keeps them apart
   static const bool fold_ln_enabled = !(getenv("VR_ENCODE_FOLD_LN") && atoi(getenv("VR_ENCODE_FOLD_LN")) == 0);
   const bool fold_ln = lnfuse && fold_ln_enabled && skinny_ln_supported(T, 3 * H, H) && I % 16 == 0;
+  // large batches (the 256-tile GEMM): the LayerNorm passes disappear into the GEMMs on both sides of them —
+  // the producing epilogue also stores f16 pre-LN rows and per-(row, 64 columns) partial sums, a tiny
+  // kernel turns those into (mean, 1/sigma), and the consuming GEMM multiplies the pre-LN rows by the
+  // gain-scaled weights and applies the statistics in its epilogue (EPI_FOLD_*). VR_ENCODE_FOLD_GEMM=0: off.
+  static const bool fold_big_enabled = !(getenv("VR_ENCODE_FOLD_GEMM") && atoi(getenv("VR_ENCODE_FOLD_GEMM")) == 0);
+  const bool fold_big = lnfuse && fold_big_enabled && T > 4 * kSkinnyM && H % 256 == 0 && enc->layers[0].cs_1 != nullptr;
+  float2* part = reinterpret_cast<float2*>(enc->lnpart);
+  const int segs = H / 64;
+  const unsigned fin_blocks = static_cast<unsigned>((T + 255) / 256);
   hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, ids_dev, cu_dev, n_seq_total,
                      tok_base, T, H, d.vocab, enc->word, enc->pos, enc->type, enc->lng, enc->lnb, d.eps,
                      lnfuse ? nullptr : enc->x, xh, xl, lnfuse ? enc->x : nullptr, lnfuse ? stat_b : nullptr);
@@ -1989,6 +2121,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     if (plain && fold_ln && li > 0)  // the previous layer's closing LayerNorm runs inside this projection
       VR_TRY(launch_skinny_ln(e, EPI_BIAS_F16, cur.pre, cur.g, cur.b, d.eps, const_cast<float2*>(cur.stat), w.s_qkv.hi,
                               w.s_qkv.unscale, w.bqkv, reinterpret_cast<half_t*>(enc->qkv), T, 3 * H, H));
+    else if (plain && fold_big && li > 0)  // xh holds the f16 PRE-LN rows the previous FFN-down epilogue stored
+      VR_TRY(launch_gemm_f16x3(e, EPI_FOLD_F16, xh, nullptr, w.s_qkv_f.hi, nullptr, w.s_qkv_f.unscale, w.c_qkv, nullptr,
+                               nullptr, reinterpret_cast<half_t*>(enc->qkv), nullptr, T, 3 * H, H, 1, cur.stat, w.cs_qkv,
+                               nullptr));
     else if (plain)  // Q, K, V as plain f16 rows for attention_f16_kernel
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_F16, xh, xl, w.s_qkv.hi, w.s_qkv.lo, w.s_qkv.unscale, w.bqkv, nullptr,
                                nullptr, reinterpret_cast<half_t*>(enc->qkv), nullptr, T, 3 * H, H, passes));
@@ -2054,9 +2190,14 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       // hidden state = LN(cur.pre): pre-LN rows alternate between the two buffers
       float* t1 = cur.pre == enc->x ? enc->tmp : enc->x;
       float2* s1 = cur.stat == stat_b ? stat_a : stat_b;
+      if (fold_big) {
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN_STATS, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre,
+                                 t1, xh, reinterpret_cast<half_t*>(part), T, H, H, 1, cur.stat, cur.g, cur.b));
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, part, T, segs, H, d.eps, s1);
+      } else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre, t1,
                                nullptr, nullptr, T, H, H, 1, cur.stat, cur.g, cur.b));
-      if (fold_ln)
+      if (fold_ln || fold_big)
         ;  // the attention-output LayerNorm runs inside the FFN-up projection below
       else if (H % 256 == 0)
         hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t1, T, H, w.ln1g, w.ln1b, d.eps,
@@ -2069,15 +2210,24 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       float2* s2 = const_cast<float2*>(cur.stat);
       if (fold_ln)
         VR_TRY(launch_skinny_ln(e, EPI_BIAS_GELU, t1, w.ln1g, w.ln1b, d.eps, s1, w.s_1.hi, w.s_1.unscale, w.b1, fh, T, I, H));
+      else if (fold_big)
+        VR_TRY(launch_gemm_f16x3(e, EPI_FOLD_GELU, xh, nullptr, w.s_1_f.hi, nullptr, w.s_1_f.unscale, w.c_1, nullptr, nullptr,
+                                 fh, nullptr, T, I, H, 1, s1, w.cs_1, nullptr));
       else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, nullptr, w.s_1.hi, nullptr, w.s_1.unscale, w.b1, nullptr, nullptr, fh,
                                nullptr, T, I, H, 1));
+      if (fold_big)
+        VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN_STATS, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre,
+                                 t2, xh, reinterpret_cast<half_t*>(part), T, H, I, 1, mid.stat, mid.g, mid.b));
+      else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre, t2,
                                nullptr, nullptr, T, H, I, 1, mid.stat, mid.g, mid.b));
       // the last LayerNorm of the network also stores its f32 rows (into the free buffer): pooling reads them
       const bool last = li + 1 == enc->layers.size();
       if (fold_ln && !last)
         ;  // this layer's closing LayerNorm runs inside the next layer's Q/K/V projection
+      else if (fold_big && !last)  // ... its statistics only
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, part, T, segs, H, d.eps, s2);
       else if (H % 256 == 0)
         hipLaunchKernelGGL(layernorm_f16_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
                            last ? t1 : static_cast<float*>(nullptr), xh, s2);
