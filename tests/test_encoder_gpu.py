@@ -201,6 +201,7 @@ def test_single_query_path_folds_layernorm_into_the_projections(gpu, name, layer
     ("e5-base-v2", 3, [128, 90, 77, 110, 45]),              # mean pooling: the very last LayerNorm stays a kernel
     ("bge-large-en-v1.5", 2, [100, 128, 60, 75]),
     ("bge-base-en-v1.5", 12, [128, 128, 64]),               # full depth through the folded path
+    ("all-MiniLM-L6-v2", 6, [128, 99, 64, 31, 77]),         # H = 384: a 256-column tile and a half one
 ])
 def test_large_batches_fold_layernorm_into_the_gemms(gpu, name, layers, lens):
     """More than 256 tokens in f16 mode: no LayerNorm pass between the GEMMs — the producing epilogue stores

@@ -1989,7 +1989,7 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
       VR_TRY(make_split(e, enc, lw.wo, HH, H, plain, &lw.s_o));
       VR_TRY(make_split(e, enc, lw.w1, static_cast<size_t>(I) * H, H, plain, &lw.s_1));
       VR_TRY(make_split(e, enc, lw.w2, static_cast<size_t>(I) * H, I, plain, &lw.s_2));
-      if (plain && H % 256 == 0) {  // operands of the folded-LayerNorm GEMMs
+      if (plain && H % 64 == 0) {  // operands of the folded-LayerNorm GEMMs
         auto fold = [&](const float* w_dev, int N, const float* g, const float* b, const float* bias, SplitWeight* sw,
                         float** colsum, float** c) -> int {
           const size_t n = static_cast<size_t>(N) * H;
@@ -2091,7 +2091,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   // kernel turns those into (mean, 1/sigma), and the consuming GEMM multiplies the pre-LN rows by the
   // gain-scaled weights and applies the statistics in its epilogue (EPI_FOLD_*). VR_ENCODE_FOLD_GEMM=0: off.
   static const bool fold_big_enabled = !(getenv("VR_ENCODE_FOLD_GEMM") && atoi(getenv("VR_ENCODE_FOLD_GEMM")) == 0);
-  const bool fold_big = lnfuse && fold_big_enabled && T > 4 * kSkinnyM && H % 256 == 0 && enc->layers[0].cs_1 != nullptr;
+  const bool fold_big = lnfuse && fold_big_enabled && T > 4 * kSkinnyM && H % 64 == 0 && enc->layers[0].cs_1 != nullptr;
   float2* part = reinterpret_cast<float2*>(enc->lnpart);
   const int segs = H / 64;
   const unsigned fin_blocks = static_cast<unsigned>((T + 255) / 256);
