@@ -101,7 +101,9 @@ def test_bulk_indexer_matches_the_per_file_sequence(native, monkeypatch):  # noq
     assert len(a_answers) == len(b_answers)
     for got, want in zip(b_answers, a_answers):
         assert len(got) == len(want)
-        assert np.allclose([s for _, s in got], [s for _, s in want], atol=2e-5)
+        # min-max fusion divides by the spread of the prefetched scores (a few 1e-2 here), so the 1e-6
+        # differences between the two GEMM paths' dense scores come back a hundredfold in the fused ones
+        assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-3)
         if [k for k, _ in got] != [k for k, _ in want]:  # only near-ties may swap
             assert sorted(k for k, _ in got[:-1]) == sorted(k for k, _ in want[:-1]) or \
                 set(k for k, _ in got) == set(k for k, _ in want)

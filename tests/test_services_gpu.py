@@ -102,7 +102,10 @@ def test_embedding_service(native, pooling):
     cos = (got * want).sum(1) / np.linalg.norm(got, axis=1)
     assert np.max(np.abs(1 - cos)) < 1e-5
     one = np.array(svc.embed_text(texts[3]))
-    assert one.shape == (shape.hidden,) and np.array_equal(one.astype(np.float32), got[3].astype(np.float32))
+    # one text alone takes the few-token kernels, the batch of 39 the large-batch ones (LayerNorm folded into
+    # the GEMMs, different summation orders): the same embedding up to the f16 mode's rounding, not the same bits
+    assert one.shape == (shape.hidden,) and abs(1.0 - float(np.dot(one, got[3]))) < 1e-6
+    assert np.max(np.abs(one - got[3])) < 1e-4
     assert np.array_equal(np.array(svc.embed_query(texts[3])), one)  # no e5 in the name: no prefixes
 
 
