@@ -86,6 +86,20 @@ def main() -> None:
     assert hits[0].metadata.file_path == "docs/file3.md" and hits[0].metadata.chunk_index == 5
 
     assert vs.delete_by_file("docs/file0.md") == 32 and vs.compact() == 32        # re-index / watcher delete, then reclaim
+
+    # the same from RAW documents: ChunkingService + both tokenisers + the fused encode/tf/append call, pipelined
+    # across file boundaries (the host stages of batch i+1 run while the GPU works on batch i)
+    from voitta_rag_amd.indexer import BulkIndexer, ParsedFile
+    raw = [ParsedFile(content="\n\n".join(" ".join(rng.choice(WORDS, size=int(rng.integers(20, 90)))) + "." for _ in range(12)),
+                      file_path=f"notes/raw{i}.txt", folder_path="notes", index_folder="notes", file_name=f"raw{i}.txt",
+                      source_modified_at=1_750_000_000 + i) for i in range(16)]
+    counts = BulkIndexer(batch_chunks=256).index_files(raw)
+    print("bulk-indexed", sum(counts.values()), "chunks cut from", len(raw), "raw documents;",
+          vs.count_by_file("notes/raw3.txt"), "of them belong to notes/raw3.txt")
+    from voitta_rag_amd.chunking import get_chunking_service
+    probe = get_chunking_service().chunk_text(raw[3].content)[1].text        # a stored chunk's own text finds itself
+    hit = vs.search(emb.embed_query(probe), limit=1, include_folders=["notes"], sparse_query=sp.embed_query(probe))[0]
+    assert (hit.metadata.file_path, hit.metadata.chunk_index) == ("notes/raw3.txt", 1), hit.metadata
     print("saved to", vs.save())                                                   # -> $VOITTA_INDEX_DIR
     print("a fresh process with VOITTA_INDEX_DIR set finds", vs.get_collection_info()["points_count"], "chunks again")
 
