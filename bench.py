@@ -379,8 +379,9 @@ def main():
             "dtype": {"f32": "f32",
                       "f16x3": "f16x3 (operands as hi+lo f16 = 22 significant bits, three f16-MFMA passes, f32 "
                                "accumulate; measured |1-cos| ~5e-8 vs the f64 oracle)",
-                      "f16": "f16 (f16 MFMA operands, f32 accumulate; attention, LayerNorm, GELU, pooling in f32; "
-                             "measured |1-cos| = 2.0e-6 vs the f64 oracle on the full 12-layer shape (tests/test_encoder_gpu.py), "
+                      "f16": "f16 (f16 MFMA operands, f32 accumulate; attention, softmax, residual stream, pooling in f32; "
+                             "LayerNorm statistics in f32, applied inside the GEMM epilogues; "
+                             "measured |1-cos| = 1e-6..2e-6 vs the f64 oracle on the full 12-layer shape (tests/test_encoder_gpu.py), "
                              "north_star tolerance 1e-4)"
                       }[args.precision],
             "data": "synthetic (seeded token ids / unit vectors; random-init N(0,0.02) weights of the named shape)",
