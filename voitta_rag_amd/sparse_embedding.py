@@ -5,55 +5,58 @@ the HIP token-count / tf kernel (vr_bm25_tf)."""
 from __future__ import annotations
 
 import logging
+from typing import Optional
 
 import numpy as np
 
 from . import bm25 as _bm25
 from .store_registry import get_engine
 
-logger = logging.getLogger(__name__)
+SPARSE_VECTOR_NAME = "bm25"  # the named sparse vector of the collection (sparse_embedding.py:9)
+_log = logging.getLogger(__name__)
 
-SPARSE_VECTOR_NAME = "bm25"  # sparse_embedding.py:9
+
+def _query_vector(query: str) -> tuple[list[int], list[float]]:
+    """Bm25.query_embed: the SET of hashed stems, every value 1.0; nothing survives
+    stop-word removal -> ``([], [])`` (sparse_embedding.py:36-37)."""
+    stems = _bm25.hashed_stems([query])[1]
+    distinct = np.unique(stems)
+    return (distinct.tolist(), [1.0] * int(distinct.size)) if stems.size else ([], [])
 
 
 class SparseEmbeddingService:
-    """Service for generating BM25 sparse embeddings on the GPU."""
+    """BM25 sparse embeddings; term weights are computed on the GPU, the text side on the host."""
 
-    def __init__(self):
-        self._model = None
+    def __init__(self) -> None:
+        self._model = None  # the engine that carries the BM25 kernels, bound on first use (:18-27)
+
+    def embed_texts(self, texts: list[str]) -> list[tuple[list[int], list[float]]]:
+        """One (indices, values) pair per text; values are Python floats (f64) as fastembed returns
+        them. Indices come out ascending (fastembed: first-occurrence order; a sparse vector is a set)."""
+        if len(texts) == 0:
+            return []
+        offsets, stems = _bm25.hashed_stems(texts)
+        return [(idx.tolist(), val.tolist()) for idx, val in self.model.bm25_tf(offsets, stems)]
+
+    def embed_query(self, query: str) -> tuple[list[int], list[float]]:
+        return _query_vector(query)
 
     @property
     def model(self):
-        """The engine that carries the BM25 kernels (lazy, like sparse_embedding.py:18-27)."""
-        if self._model is None:
-            logger.info("Binding BM25 sparse embedding to the native engine")
-            self._model = get_engine()
-        return self._model
-
-    def embed_query(self, query: str) -> tuple[list[int], list[float]]:
-        """(indices, values): the set of token ids, every value 1.0 (Bm25.query_embed, SURVEY a7);
-        ``([], [])`` when nothing survives stop-word removal (sparse_embedding.py:36-37)."""
-        _, ids = _bm25.hashed_stems([query])
-        if ids.size == 0:
-            return [], []
-        uniq = np.unique(ids)
-        return uniq.tolist(), [1.0] * int(uniq.size)
-
-    def embed_texts(self, texts: list[str]) -> list[tuple[list[int], list[float]]]:
-        """List of (indices, values); values are Python floats (f64) as fastembed returns them.
-        Indices come out ascending (fastembed: first-occurrence order; a sparse vector is a set)."""
-        if not texts:
-            return []
-        off, ids = _bm25.hashed_stems(texts)
-        rows = self.model.bm25_tf(off, ids)
-        return [(i.tolist(), v.tolist()) for i, v in rows]
+        engine = self._model
+        if engine is None:
+            _log.info("Binding BM25 sparse embedding to the native engine")
+            engine = self._model = get_engine()
+        return engine
 
 
-_sparse_embedding_service: SparseEmbeddingService | None = None
+_sparse_embedding_service: Optional[SparseEmbeddingService] = None
 
 
 def get_sparse_embedding_service() -> SparseEmbeddingService:
+    """The process-wide instance (sparse_embedding.py:57-62)."""
     global _sparse_embedding_service
-    if _sparse_embedding_service is None:
-        _sparse_embedding_service = SparseEmbeddingService()
-    return _sparse_embedding_service
+    service = _sparse_embedding_service
+    if service is None:
+        service = _sparse_embedding_service = SparseEmbeddingService()
+    return service
