@@ -10,6 +10,7 @@ stream of files with the same stored result (same chunks, payload fields, vector
   pay a GPU launch sequence of its own),
 * the host stages — chunking (vr_chunk_texts), WordPiece (vr_wordpiece_encode) and the BM25 tokeniser
   (vr_bm25_tokenize), all on every host thread — run on a producer thread for batch i+1 while
+* point ids and payload dicts of batch i+1 are made there too (VectorStoreService.prepare_rows), and
 * the GPU stages of batch i run as ONE engine call (vr_index_batch: encode → tf → append, nothing
   leaves HBM) on the caller's thread. ctypes drops the GIL inside both, so they overlap.
 
@@ -53,6 +54,7 @@ class _Batch:
     bm_ids: object
     bm_off: object
     counts: dict[str, int]
+    rows: tuple | None = None  # (point ids, payload dicts) made on the producer thread
 
 
 class BulkIndexer:
@@ -76,7 +78,8 @@ class BulkIndexer:
         bm_ids = bm_off = None
         if self.sparse:
             bm_off, bm_ids = _bm25.hashed_stems(texts)  # BM25 sees the chunk text itself (indexing.py:529-530)
-        return _Batch(texts, metadatas, wp_ids, wp_off, bm_ids, bm_off, counts)
+        rows = self.vector_store.prepare_rows(texts, metadatas) if hasattr(self.vector_store, "prepare_rows") else None
+        return _Batch(texts, metadatas, wp_ids, wp_off, bm_ids, bm_off, counts, rows)
 
     def _batches(self, files: Iterable[ParsedFile]) -> Iterator[_Batch]:
         texts: list[str] = []
@@ -117,7 +120,7 @@ class BulkIndexer:
             cut(pending)
         yield from drain(True)
         if counts:  # files that produced no chunk at all after the last batch
-            yield _Batch([], [], None, None, None, None, counts)
+            yield _Batch([], [], None, None, None, None, counts, None)
 
     # ---- the pipeline --------------------------------------------------------------------------------
     def index_files(self, files: Iterable[ParsedFile]) -> dict[str, int]:
@@ -146,8 +149,12 @@ class BulkIndexer:
                 if batch is None:
                     break
                 if batch.texts:
-                    self.vector_store.index_chunks(batch.texts, batch.metadatas, batch.wp_ids, batch.wp_off,
-                                                   batch.bm_ids, batch.bm_off)
+                    if batch.rows is not None:
+                        self.vector_store.index_chunks(batch.texts, batch.metadatas, batch.wp_ids, batch.wp_off,
+                                                       batch.bm_ids, batch.bm_off, rows=batch.rows)
+                    else:
+                        self.vector_store.index_chunks(batch.texts, batch.metadatas, batch.wp_ids, batch.wp_off,
+                                                       batch.bm_ids, batch.bm_off)
                 done.update(batch.counts)
         finally:
             while producer.is_alive():  # unblock a producer stuck on a full queue after an error here

@@ -324,19 +324,29 @@ class VectorStoreService:
         logger.info(f"Stored {n} chunks in the native engine")
         return ids
 
+    @classmethod
+    def prepare_rows(cls, texts: list[str], metadatas: list[ChunkMetadata]) -> tuple[list[str], list[dict]]:
+        """Point ids and payload dicts of a batch — the pure part of the host table's work. BulkIndexer calls
+        it on its producer thread, so that it runs beside the previous batch's GPU call instead of after it."""
+        ids = [str(uuid.uuid4()) for _ in texts]  # vector_store.py:256
+        return ids, [cls._payload_of(text, metadata) for text, metadata in zip(texts, metadatas)]
+
     def index_chunks(self, texts: list[str], metadatas: list[ChunkMetadata], wp_ids, wp_off,
-                     bm_ids=None, bm_off=None) -> list[str]:
+                     bm_ids=None, bm_off=None, rows: tuple[list[str], list[dict]] | None = None) -> list[str]:
         """The fused form of the three calls of IndexingService._index_file_standard —
         ``embedder.embed_texts`` + ``sparse_embedder.embed_texts`` + ``store_chunks``
         (indexing.py:527-530,560) — for a caller that hands over token ids instead of vectors: WordPiece
         ids (``wp_ids`` / ``wp_off``, [CLS] … [SEP] per chunk) and hashed BM25 stems (``bm_ids`` /
         ``bm_off``, or None for a dense-only store). Encode, tf weighting and the append run in ONE engine
         call (vr_index_batch) and nothing leaves HBM; the stored rows, payloads and scores are those the
-        three calls would have produced. Needs the encoder loaded into this store's engine."""
+        three calls would have produced. Needs the encoder loaded into this store's engine.
+        ``rows``: the result of ``prepare_rows`` for this batch, when the caller made it ahead of time."""
         n = len(texts)
         if n == 0:
             return []
         assert len(metadatas) == n
+        ids, payloads = rows if rows is not None else self.prepare_rows(texts, metadatas)
+        assert len(ids) == n and len(payloads) == n
         col = self._col
         with col.lock:
             folder = np.array([col.folder_id(m.folder_path, True) for m in metadatas], np.int32)
@@ -348,13 +358,10 @@ class VectorStoreService:
             first = self.client.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
                                             created=created, modified=modified)
             assert first == len(col.payload), "host table and engine rows diverged"
-            ids = []
-            for i, (text, metadata) in enumerate(zip(texts, metadatas)):
-                point_id = str(uuid.uuid4())
-                ids.append(point_id)
-                col.ids.append(point_id)
-                col.payload.append(self._payload_of(text, metadata))
-                col.row_of[point_id] = first + i
+            col.ids.extend(ids)
+            col.payload.extend(payloads)
+            col.row_of.update(zip(ids, range(first, first + n)))
+            for i, metadata in enumerate(metadatas):
                 col.rows_by_file.setdefault(metadata.file_path, []).append(first + i)
         return ids
 
