@@ -342,6 +342,15 @@ int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd,
                    int32_t limit, double sparse_weight, int32_t json_scores,
                    int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
 
+/* Reciprocal-rank fusion of the same two lists (host, no GPU): the arithmetic of vr_search_hybrid's
+ * VR_FUSION_RRF mode in isolation. The reference does not fuse this way — its own note says why
+ * (vector_store.py:638-639: Qdrant's prefetch + fusion is RRF-only, hence the weighted min-max path) —
+ * north_star names it, so it is offered and checked against oracle/fusion.py::rrf_fuse:
+ * score(id) = sum over the lists holding id of 1 / (position + 2), position counted from 0 [EXT: the
+ * Qdrant server's RRF]; ties in the fused score go to the lower row id. */
+int vr_fuse_rrf(const int64_t* d_rows, int32_t nd, const int64_t* s_rows, int32_t ns, int32_t limit,
+                int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
+
 #ifdef __cplusplus
 }
 #endif

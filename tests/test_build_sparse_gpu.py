@@ -110,3 +110,81 @@ def test_points_without_text_get_no_sparse_vector(native):  # noqa: F811
     vs = get_vector_store()
     _, n_points = vs.client.sparse_stats(np.zeros(1, np.int32))
     assert n_points == 3  # the IDF's N counts the three points that carry a sparse vector
+
+
+def test_migrated_collection_against_the_bm25_oracle(native):  # noqa: F811
+    """The target of the migration checked against oracle/bm25.py + oracle_core, NOT against a second HIP
+    collection (scripts/build_sparse_vectors.py:153-194): every point with text carries exactly the sparse vector
+    the oracle computes from the STORED text, a point without text carries none and does not count towards the
+    IDF's N, document frequencies follow, sparse and hybrid rankings and their f32 / f64 scores are the oracle's,
+    and ids, payloads and dense rows carry over bit for bit."""
+    from oracle import bm25 as obm
+    from oracle import core as ocore
+    from oracle import fusion as ofus
+    from voitta_rag_amd.build_sparse import build_sparse_vectors
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import get_vector_store
+
+    native()
+    rng = np.random.default_rng(33)
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    texts = _texts(rng, 140)
+    ids = _index(vs, emb, sp, texts, with_sparse=False)
+    lost = [4, 17, 18, 99]  # payloads whose text was lost: skipped by the reference (:158-165)
+    for r in lost:
+        vs._col.payload[r]["text"] = ""
+    vs.delete_by_file("b/f1.md")  # rows 11, 13, 15, 17, 19: tombstones in the source are not copied
+    src_rows = list(vs._col.live_rows())
+    assert len(src_rows) == len(texts) - 5
+    dense_before = vs.client.get_dense(np.array(src_rows, np.int64))
+    payload_before = [dict(vs._col.payload[r]) for r in src_rows]
+    ids_before = [vs._col.ids[r] for r in src_rows]
+
+    stats = build_sparse_vectors(batch_size=37, switch=True)  # odd batch size: runs with/without text cross batches
+    n = len(src_rows)
+    n_lost = sum(1 for r in src_rows if r in lost)
+    assert (stats["processed"], stats["inserted"], stats["skipped"]) == (n, n, n_lost)
+
+    vs = get_vector_store()
+    e = vs.client
+    assert e.count() == (n, n)
+    # carry-over (:176-194): ids, payloads, dense bits, in the source's order
+    assert [vs._col.ids[i] for i in range(n)] == ids_before and set(ids_before) <= set(ids)
+    assert [vs._col.payload[i] for i in range(n)] == payload_before
+    assert np.array_equal(e.get_dense(np.arange(n)).view(np.uint32), dense_before.view(np.uint32))
+
+    # the oracle's sparse rows from the STORED texts (f64 tf -> f32 as stored); no text -> no sparse vector
+    want_rows = []
+    for p in payload_before:
+        if not p["text"]:
+            want_rows.append(None)
+            continue
+        m = obm.term_frequency(obm.stems(p["text"]))
+        idx = np.array(sorted(m), np.int32)
+        want_rows.append((idx, np.array([m[int(t)] for t in idx], np.float64).astype(np.float32)))
+    df_want, n_points = ocore.document_frequencies(want_rows)
+    assert n_points == n - n_lost
+    probe = np.array(sorted(df_want) + [123456789], np.int32)
+    df_got, n_got = e.sparse_stats(probe)
+    assert n_got == n_points
+    assert [int(v) for v in df_got] == [df_want.get(int(t), 0) for t in probe]
+
+    stored = e.get_dense(np.arange(n))
+    for qtext in ("vector database index", "running happily", "memory bandwidth kernel", "hybrid fusion ranking", "chunk"):
+        qi, qv = obm.query_embed(qtext)
+        want = ocore.sparse_scores(want_rows, qi, qv)
+        for k in (10, 30):
+            wr, ws = ocore.topk(want, k)
+            gr, gs = e.search_sparse(qi, qv, k)
+            assert np.array_equal(gr, wr), qtext
+            assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), qtext
+        assert not any(want_rows[int(r)] is None for r in wr)  # a point without text never answers a sparse query
+        q = np.asarray(emb.embed_query(qtext), np.float32)
+        dsc = ocore.dense_scores(ocore.cosine_preprocess(q[None]), stored)[0]
+        dr, ds = ocore.topk(dsc, 30)
+        sr, ss = ocore.topk(want, 30)
+        fused = ofus.hybrid_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())), 10, 0.4, "json")
+        got = vs.search(q.tolist(), limit=10, sparse_query=(qi, qv), sparse_weight=0.4)
+        assert [vs._col.row_of[c.id] for c in got] == [r for r, _, _ in fused]
+        assert [c.score for c in got] == [s for _, s, _ in fused]

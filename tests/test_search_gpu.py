@@ -164,6 +164,15 @@ def test_sparse_and_hybrid_bit_exact(gpu):
                 assert rows.tolist() == [r for r, _, _ in fused]
                 assert scores.tolist() == [s for _, s, _ in fused]
                 assert fd.astype(bool).tolist() == [f for _, _, f in fused]
+                # the same two top-(3 limit) lists fused by reciprocal rank (VR_FUSION_RRF, north_star's mode;
+                # the reference's note on it: vector_store.py:638-639)
+                from voitta_rag_amd.engine import VR_FUSION_RRF
+
+                rr = ofus.rrf_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())), limit)
+                rows, scores, fd = e.search_hybrid(q, qi, qv, limit, w, fusion=VR_FUSION_RRF)
+                assert rows.tolist() == [r for r, _, _ in rr]
+                assert scores.tolist() == [s for _, s, _ in rr]
+                assert fd.astype(bool).tolist() == [f for _, _, f in rr]
         # second round: after deletes the document frequencies and N must follow
         dead = rng.choice(n, size=400, replace=False)
         e.delete_rows(dead)

@@ -27,12 +27,12 @@ def _vocab():
     return list(dict.fromkeys(v))
 
 
-def _checkpoint(tmp_path, name, pooling, seed=5):
+def _checkpoint(tmp_path, name, pooling, seed=5, dims=(2, 128, 4, 256), max_seq=32):
     d = tmp_path / name
     (d / "1_Pooling").mkdir(parents=True)
     (d / "2_Normalize").mkdir()
     vocab = _vocab()
-    shape = obert.BertShape(2, 128, 4, 256, vocab=len(vocab), max_pos=64)
+    shape = obert.BertShape(*dims, vocab=len(vocab), max_pos=max(64, max_seq))
     (d / "config.json").write_text(json.dumps({
         "model_type": "bert", "hidden_size": shape.hidden, "num_hidden_layers": shape.layers,
         "num_attention_heads": shape.heads, "intermediate_size": shape.intermediate, "vocab_size": shape.vocab,
@@ -44,7 +44,7 @@ def _checkpoint(tmp_path, name, pooling, seed=5):
     (d / "1_Pooling" / "config.json").write_text(json.dumps({
         "word_embedding_dimension": shape.hidden, "pooling_mode_cls_token": pooling == "cls",
         "pooling_mode_mean_tokens": pooling == "mean"}))
-    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 32, "do_lower_case": True}))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": max_seq, "do_lower_case": True}))
     (d / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
     w = obert.random_weights(shape, seed)
     from safetensors.numpy import save_file
@@ -57,8 +57,8 @@ def _checkpoint(tmp_path, name, pooling, seed=5):
 def native(monkeypatch, tmp_path, gpu):
     from voitta_rag_amd import config, embedding, sparse_embedding, store_registry, vector_store
 
-    def setup(name="mini-model", pooling="mean"):
-        path, shape, w, vocab = _checkpoint(tmp_path, name, pooling)
+    def setup(name="mini-model", pooling="mean", **kw):
+        path, shape, w, vocab = _checkpoint(tmp_path, name, pooling, **kw)
         monkeypatch.setenv("EMBEDDING_MODEL", path)
         monkeypatch.setenv("EMBEDDING_DIMENSION", str(shape.hidden))
         config.get_settings.cache_clear()

@@ -123,6 +123,7 @@ SIGNATURES = {
     "vr_load": (C.c_int, [_vp, C.c_char_p]),
     "vr_fuse_minmax": (C.c_int, [_i64p, _fp, C.c_int32, _i64p, _fp, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                  _i64p, _dp, _i32p, _i32p]),
+    "vr_fuse_rrf": (C.c_int, [_i64p, C.c_int32, _i64p, C.c_int32, C.c_int32, _i64p, _dp, _i32p, _i32p]),
 }
 
 

@@ -715,4 +715,10 @@ int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd, con
                      out_rows, out_scores, out_from_dense, out_count);
 }
 
+int vr_fuse_rrf(const int64_t* d_rows, int32_t nd, const int64_t* s_rows, int32_t ns, int32_t limit,
+                int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count) {
+  VR_CHECK(nd >= 0 && ns >= 0 && out_rows && out_scores && out_count, "bad arguments");
+  return fuse_rrf(d_rows, nd, s_rows, ns, limit, 0.0, out_rows, out_scores, out_from_dense, out_count);
+}
+
 }  // extern "C"

@@ -1080,6 +1080,386 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #undef VR_GLDS_STAGE
 }
 
+// ---- the 256x256 f16 product with a ping-pong main loop ----------------------------------------------
+//
+// Same tile, LDS image, swizzle, persistent tile walk and epilogues as gemm_f16x3_256_kernel<EPI, 1>; what
+// changes is WHEN things happen inside a 64-deep K-tile. There every wave read fragments, multiplied and
+// waited for the next K-tile's loads in step with its SIMD partner (one barrier and one vmcnt(0) per K-tile):
+// while both read LDS or waited, the matrix pipe of the SIMD idled (64 % MFMA issue in the main loop). Here
+//   * a K-tile is four PHASES, one 64x32 quadrant of the wave's 128x64 tile each (16 MFMAs over both 32-deep
+//     steps): a READ segment (the phase's fragment reads + two direct-to-LDS loads of the next K-tile) and
+//     an MFMA segment, each closed by a raw s_barrier;
+//   * waves 4-7 (the second wave of every SIMD) run one segment behind waves 0-3, so at any time one wave of
+//     a SIMD multiplies while its partner reads and loads: the partner's LDS latency, load issue and barrier
+//     wait sit under 256 cycles of MFMAs instead of beside them;
+//   * the next K-tile arrives in four half-tiles issued in the order they are needed (rows of quadrant
+//     rows 0-63 of A, quadrant columns 0-31 of W, columns 32-63, rows 64-127), each waited for with a COUNTED
+//     vmcnt two to three phases after its issue (never vmcnt(0) in the loop) — two half-tiles stay in flight
+//     across every barrier. A wait sits in the READ segment of the phase BEFORE the one that reads the data, so
+//     that every wave's wait and one more barrier lie between a load and any wave's read of it.
+// Accumulation order per output element is unchanged (k ascending), so the result is bit-identical to
+// gemm_f16x3_256_kernel<EPI, 1>. Needs an even number of K-tiles (K % 128 == 0: every supported width).
+// Diagnostic build only (make diag -> libvoitta_engine_diag.so, selected with VOITTA_ENGINE_LIB): VR_GEMM_DIAG in the
+// environment switches parts of gemm_f16_pp_kernel off at run time, so that one box can time the kernel without
+// its loads (1), its epilogue (2), its MFMAs (4), its fragment reads (8) or its barriers (16). Results are then
+// wrong by construction; only the timings mean anything. The shipped library compiles none of this.
+#ifdef VR_GEMM_DIAG_BUILD
+__device__ int g_gemm_diag = 0;
+#define VR_DIAG(bit) ((diag_bits & (bit)) != 0)
+#else
+#define VR_DIAG(bit) false
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
+    const half_t* __restrict__ Ah, const half_t* __restrict__ Wh, const float* __restrict__ bias,
+    const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
+    int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b) {
+  __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
+  const int tiles_n = (N + GBN - 1) / GBN;
+  const int tiles_m = (M + GBM - 1) / GBM;
+  const int total = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int local = (G % 8 == 0) ? (static_cast<int>(blockIdx.x) % 8) * (G / 8) + static_cast<int>(blockIdx.x) / 8
+                                 : static_cast<int>(blockIdx.x);
+  auto coords = [&](int t, int& bm_, int& bn_) {
+    const int per_group = kGroupM256 * tiles_n;
+    const int group = t / per_group;
+    const int within = t - group * per_group;
+    const int gm = min(kGroupM256, tiles_m - group * kGroupM256);
+    bm_ = (group * kGroupM256 + within % gm) * GBM;
+    bn_ = (within / gm) * GBN;
+  };
+  int tile = local;
+  if (tile >= total) return;  // block-uniform
+  int bm, bn;
+  coords(tile, bm, bn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // staging: one direct-to-LDS load moves 8 rows x 128 B; lane -> row (lane >> 3) of the 8, LDS chunk
+  // (lane & 7), source chunk (lane & 7) ^ ((row >> 1) & 7). Wave w stages A rows 8w + {0, 128} (the rows
+  // of quadrant rows 0-63 of both wave rows: "A lo"), 8w + {64, 192} ("A hi"), and W rows
+  // 64 (w >> 2) + 8 (w & 3) + {0, 128} (quadrant columns 0-31 of all four wave columns: "W lo"), + {32, 160}
+  // ("W hi"): every wave issues two loads per half-tile, so one vmcnt count serves all waves.
+  const int srow = lane >> 3;
+  const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  const int ra = wave * 8 + srow;
+  const int rw = 64 * (wave >> 2) + 8 * (wave & 3) + srow;
+  const half_t *g_a0, *g_a1, *g_a2, *g_a3, *g_w0, *g_w1, *g_w2, *g_w3;
+  auto set_ptrs = [&](int bm_, int bn_) {
+    g_a0 = Ah + static_cast<int64_t>(min(bm_ + ra, M - 1)) * K + schunk;        // lo
+    g_a1 = Ah + static_cast<int64_t>(min(bm_ + ra + 128, M - 1)) * K + schunk;  // lo
+    g_a2 = Ah + static_cast<int64_t>(min(bm_ + ra + 64, M - 1)) * K + schunk;   // hi
+    g_a3 = Ah + static_cast<int64_t>(min(bm_ + ra + 192, M - 1)) * K + schunk;  // hi
+    g_w0 = Wh + static_cast<int64_t>(min(bn_ + rw, N - 1)) * K + schunk;        // lo
+    g_w1 = Wh + static_cast<int64_t>(min(bn_ + rw + 128, N - 1)) * K + schunk;  // lo
+    g_w2 = Wh + static_cast<int64_t>(min(bn_ + rw + 32, N - 1)) * K + schunk;   // hi
+    g_w3 = Wh + static_cast<int64_t>(min(bn_ + rw + 160, N - 1)) * K + schunk;  // hi
+  };
+  set_ptrs(bm, bn);
+  // wave-uniform LDS destinations (halfs, inside a stage buffer)
+  const int da0 = wave * 8 * 64, da1 = da0 + 128 * 64, da2 = da0 + 64 * 64, da3 = da0 + 192 * 64;
+  const int dw0 = 256 * 64 + (64 * (wave >> 2) + 8 * (wave & 3)) * 64, dw1 = dw0 + 128 * 64, dw2 = dw0 + 32 * 64,
+            dw3 = dw0 + 160 * 64;
+
+  f32x4 acc[8][4];
+  // fragments (v_mfma_f32_16x16x32_f16): lane l supplies row (l & 15), k = 8 (l >> 4) + j of a 32-deep step;
+  // step kk of the K-tile is chunk 4 kk + (l >> 4) of the row, stored at chunk ^ ((row >> 1) & 7)
+  const int frow = lane & 15;
+  const int fsw = (frow >> 1) & 7;
+  const int fq = lane >> 4;
+  const int pa = (wm * 128 + frow) * 64;
+  const int pw = 256 * 64 + (wn * 64 + frow) * 64;
+  const int fk0 = (fq ^ fsw) * 8, fk1 = ((4 + fq) ^ fsw) * 8;
+
+  const int nk = K / 64;  // even
+#ifdef VR_GEMM_DIAG_BUILD
+  const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
+#endif
+#define VR_PP_BARRIER()                                      \
+  do {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    if (!VR_DIAG(16)) __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);                       \
+  } while (0)
+#define VR_PP_HARD_BARRIER()                 \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+#define VR_PP_VMCNT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+
+  // prologue: K-tile 0 of the first tile, all eight pieces, into buffer 0
+  glds16(g_a0, lds + da0);
+  glds16(g_a1, lds + da1);
+  glds16(g_w0, lds + dw0);
+  glds16(g_w1, lds + dw1);
+  glds16(g_w2, lds + dw2);
+  glds16(g_w3, lds + dw3);
+  glds16(g_a2, lds + da2);
+  glds16(g_a3, lds + da3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VR_PP_BARRIER();
+  if (wm == 1) VR_PP_BARRIER();  // waves 4-7 run one segment behind from here on
+
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int next = tile + G;
+    const bool has_next = next < total;
+    int nbm = bm, nbn = bn;
+    if (has_next) coords(next, nbm, nbn);
+
+    // one K-tile out of stage buffer B; the next K-tile (or K-tile 0 of the next tile, or — at the very
+    // end — a harmless re-load) goes into buffer B ^ 1
+    auto ktile = [&](auto bsel, int kt) {
+      constexpr int B = decltype(bsel)::value;
+      const half_t* st = lds + B * kStageHalfs;
+      half_t* nd = lds + (B ^ 1) * kStageHalfs;
+      const bool lastk = kt == nk - 1;
+      if (lastk && has_next) set_ptrs(nbm, nbn);
+      const int koff = lastk ? 0 : (kt + 1) * 64;
+      f16x8 af[4][2], bf[2][2];
+#ifdef VR_GEMM_DIAG_BUILD
+      for (int i = 0; i < 4; ++i) af[i][0] = af[i][1] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+      for (int j = 0; j < 2; ++j) bf[j][0] = bf[j][1] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+#endif
+      // ---- phase 0: quadrant rows 0-63 x columns 0-31 ------------------------------------------------
+      if (!VR_DIAG(1)) glds16(g_a0 + koff, nd + da0);
+      if (!VR_DIAG(1)) glds16(g_a1 + koff, nd + da1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!VR_DIAG(8)) bf[j][0] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fk0);
+        if (!VR_DIAG(8)) bf[j][1] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fk1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!VR_DIAG(8)) af[i][0] = *reinterpret_cast<const f16x8*>(st + pa + i * 16 * 64 + fk0);
+        if (!VR_DIAG(8)) af[i][1] = *reinterpret_cast<const f16x8*>(st + pa + i * 16 * 64 + fk1);
+      }
+      if (kt != 0) VR_PP_VMCNT4();  // W hi of this K-tile has landed (K-tile 0 was waited for whole)
+      VR_PP_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!VR_DIAG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      VR_PP_BARRIER();
+      // ---- phase 1: rows 0-63 x columns 32-63 ---------------------------------------------------------
+      if (!VR_DIAG(1)) glds16(g_w0 + koff, nd + dw0);
+      if (!VR_DIAG(1)) glds16(g_w1 + koff, nd + dw1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!VR_DIAG(8)) bf[j][0] = *reinterpret_cast<const f16x8*>(st + pw + (2 + j) * 16 * 64 + fk0);
+        if (!VR_DIAG(8)) bf[j][1] = *reinterpret_cast<const f16x8*>(st + pw + (2 + j) * 16 * 64 + fk1);
+      }
+      if (kt != 0) VR_PP_VMCNT4();  // A hi of this K-tile has landed
+      VR_PP_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!VR_DIAG(4)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[i][2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      VR_PP_BARRIER();
+      // ---- phase 2: rows 64-127 x columns 32-63 -------------------------------------------------------
+      if (!VR_DIAG(1)) glds16(g_w2 + koff, nd + dw2);
+      if (!VR_DIAG(1)) glds16(g_w3 + koff, nd + dw3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!VR_DIAG(8)) af[i][0] = *reinterpret_cast<const f16x8*>(st + pa + (4 + i) * 16 * 64 + fk0);
+        if (!VR_DIAG(8)) af[i][1] = *reinterpret_cast<const f16x8*>(st + pa + (4 + i) * 16 * 64 + fk1);
+      }
+      VR_PP_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!VR_DIAG(4)) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[4 + i][2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      VR_PP_BARRIER();
+      // ---- phase 3: rows 64-127 x columns 0-31 (W fragments read again: holding them costs 16 VGPRs) ----
+      if (!VR_DIAG(1)) glds16(g_a2 + koff, nd + da2);
+      if (!VR_DIAG(1)) glds16(g_a3 + koff, nd + da3);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!VR_DIAG(8)) bf[j][0] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fk0);
+        if (!VR_DIAG(8)) bf[j][1] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * 64 + fk1);
+      }
+      VR_PP_VMCNT4();  // A lo and W lo of the next K-tile have landed; W hi and A hi stay in flight
+      VR_PP_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!VR_DIAG(4)) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      VR_PP_BARRIER();
+    };
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, kt);
+      ktile(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // Epilogue (as gemm_f16x3_256_kernel): through this wave's own region of stage buffer 1 — the buffer of
+    // the last K-tile, free now; the next tile's K-tile 0 sits in buffer 0. W hi / A hi of that K-tile may
+    // still be in flight: they are waited for HERE, before this wave's stores queue up behind them (vmcnt
+    // retires in order: a counted wait in the next main loop would otherwise wait for the stores too).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!VR_DIAG(2)) {
+    constexpr int SLD = 64 + 4;
+    float* stage = reinterpret_cast<float*>(lds) + (kStageHalfs / 2) + wave * (16 * SLD);
+    const int c4 = (lane & 15) * 4;
+    const int gcol = bn + wn * 64 + c4;
+    const bool col_ok = gcol < N;
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + (col_ok ? gcol : 0));
+    constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
+    constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS;
+    constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
+    constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
+    float4 lg4 = make_float4(0.f, 0.f, 0.f, 0.f), lb4 = lg4;
+    if (kResidLN || kFold) lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
+    if (kResidLN) lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
+    float4 r4[2][4];
+    float2 st4[2][4];
+    auto fetch_residual = [&](int pc, float4 (&r)[4], float2 (&st)[4]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t rr = min(bm + wm * 128 + 16 * pc + (lane >> 4) + 4 * it, M - 1);
+        if (kResidual) r[it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
+        if (kResidLN || kFold) st[it] = ln_stat[rr];
+      }
+    };
+    if (kResidual || kFold) fetch_residual(0, r4[0], st4[0]);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      const int row0 = bm + wm * 128 + 16 * pc + (lane >> 4);
+      if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(4 * (lane >> 4) + r) * SLD + j * 16 + (lane & 15)] = acc[pc][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      auto emit = [&](int it) {
+        const int lr = it * 4 + (lane >> 4);
+        const int grow = row0 + 4 * it;
+        float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
+        const bool ok = grow < M && col_ok;
+        if (!kStats && !ok) return;
+        if (kFold) {
+          const float2 st = st4[pc & 1][it];
+          v.x = fmaf(fmaf(v.x, unscale, -(st.x * lg4.x)), st.y, b4.x);
+          v.y = fmaf(fmaf(v.y, unscale, -(st.x * lg4.y)), st.y, b4.y);
+          v.z = fmaf(fmaf(v.z, unscale, -(st.x * lg4.z)), st.y, b4.z);
+          v.w = fmaf(fmaf(v.w, unscale, -(st.x * lg4.w)), st.y, b4.w);
+        } else {
+          v.x = v.x * unscale + b4.x;
+          v.y = v.y * unscale + b4.y;
+          v.z = v.z * unscale + b4.z;
+          v.w = v.w * unscale + b4.w;
+        }
+        const int64_t o = static_cast<int64_t>(grow) * N + gcol;
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU) {
+          const f32x2 g01 = gelu_poly2(f32x2{v.x, v.y});
+          const f32x2 g23 = gelu_poly2(f32x2{v.z, v.w});
+          float g[4] = {g01.x, g01.y, g23.x, g23.y};
+          half_t h[4], l[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) split_f16(g[c], h[c], l[c]);
+          *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+        } else if (EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16) {
+          half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
+                         static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
+                         static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
+                         static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
+          *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+        } else {
+          if (EPI == EPI_BIAS_RESIDUAL) {
+            v.x += r4[pc & 1][it].x;
+            v.y += r4[pc & 1][it].y;
+            v.z += r4[pc & 1][it].z;
+            v.w += r4[pc & 1][it].w;
+          }
+          if (kResidLN) {
+            const float2 st = st4[pc & 1][it];
+            v.x += ln_apply(r4[pc & 1][it].x, st.x, st.y, lg4.x, lb4.x);
+            v.y += ln_apply(r4[pc & 1][it].y, st.x, st.y, lg4.y, lb4.y);
+            v.z += ln_apply(r4[pc & 1][it].z, st.x, st.y, lg4.z, lb4.z);
+            v.w += ln_apply(r4[pc & 1][it].w, st.x, st.y, lg4.w, lb4.w);
+          }
+          if (!kStats) {
+            *reinterpret_cast<float4*>(C + o) = v;
+          } else {
+            float s1 = 0.0f, s2 = 0.0f;
+            if (ok) {
+              *reinterpret_cast<float4*>(C + o) = v;
+              half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
+                             static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
+                             static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
+                             static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
+              *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
+              s1 = (v.x + v.y) + (v.z + v.w);
+              s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+              s1 += __shfl_xor(s1, off);
+              s2 += __shfl_xor(s2, off);
+            }
+            const int seg = (bn + wn * 64) >> 6;
+            if ((lane & 15) == 0 && grow < M && seg < (N >> 6))
+              reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(s1, s2);
+          }
+        }
+      };
+#pragma unroll
+      for (int it = 0; it < 4; ++it) emit(it);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
+      float t = 0.0f;
+      for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      C[0] = t;
+    }
+    if (!has_next) break;
+    tile = next;
+    bm = nbm;
+    bn = nbn;
+    // every wave has left the staging region (buffer 1) before any wave's first load of the next tile's
+    // K-tile 1 lands in it: waves 0-3 run a segment ahead, so TWO barriers separate the two
+    VR_PP_BARRIER();
+    VR_PP_BARRIER();
+  }  // tiles
+  if (wm == 0) VR_PP_BARRIER();  // pairs with the extra barrier waves 4-7 took at the start
+#undef VR_PP_BARRIER
+#undef VR_PP_VMCNT4
+}
+
 // ---- skinny product for M <= 256 rows (one query, a handful of sequences) ---------------------------
 //
 // With a few rows the 256x256 kernel leaves the chip empty (N / 256 blocks, each walking all of K:
@@ -1321,6 +1701,33 @@ static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const
 #undef VR_LAUNCH_256
 }
 
+static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Wh, const float* bias,
+                      const float* R, float* C, half_t* Ch, half_t* Cl, int M, int N, int K, float unscale,
+                      const float2* ln_stat, const float* ln_g, const float* ln_b) {
+#ifdef VR_GEMM_DIAG_BUILD
+  static bool diag_set = false;
+  if (!diag_set) {
+    const int v = getenv("VR_GEMM_DIAG") ? atoi(getenv("VR_GEMM_DIAG")) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_diag), &v, sizeof(int));
+    diag_set = true;
+  }
+#endif
+#define VR_LAUNCH_PP(E)                                                                                        \
+  hipLaunchKernelGGL((gemm_f16_pp_kernel<E>), dim3(grid), dim3(512), 0, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, \
+                     unscale, ln_stat, ln_g, ln_b)
+  switch (epi) {
+    case EPI_BIAS: VR_LAUNCH_PP(EPI_BIAS); break;
+    case EPI_BIAS_GELU: VR_LAUNCH_PP(EPI_BIAS_GELU); break;
+    case EPI_BIAS_F16: VR_LAUNCH_PP(EPI_BIAS_F16); break;
+    case EPI_BIAS_RESIDUAL_LN: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL_LN); break;
+    case EPI_FOLD_F16: VR_LAUNCH_PP(EPI_FOLD_F16); break;
+    case EPI_FOLD_GELU: VR_LAUNCH_PP(EPI_FOLD_GELU); break;
+    case EPI_BIAS_RESIDUAL_LN_STATS: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL_LN_STATS); break;
+    default: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL); break;
+  }
+#undef VR_LAUNCH_PP
+}
+
 // The skinny GEMM of a handful of tokens (M <= 16) with the LayerNorm IN FRONT of it folded in: the
 // activation operand is built from the pre-LayerNorm f32 rows instead of being read as f16 rows that a
 // LayerNorm launch wrote a few microseconds earlier. Every block recomputes the (mean, 1/sigma) of the
@@ -1524,7 +1931,11 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
     }
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     const int grid256 = std::min(tiles, n_cu);
-    if (passes == 1)
+    // f16 mode: the ping-pong main loop (gemm_f16_pp_kernel); VR_GEMM_PP=0 keeps the one-barrier-per-K-tile loop
+    static const bool pp_on = !(getenv("VR_GEMM_PP") && atoi(getenv("VR_GEMM_PP")) == 0);
+    if (passes == 1 && pp_on && K % 128 == 0)
+      launch_pp(epi, grid256, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
+    else if (passes == 1)
       launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
     else
       launch_256<3>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);

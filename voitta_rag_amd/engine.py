@@ -389,3 +389,17 @@ def fuse_minmax(d_rows, d_scores, s_rows, s_scores, limit: int, sparse_weight: f
                              _ptr(ss, C.c_float), sr.shape[0], limit, float(sparse_weight), int(json_scores),
                              _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
     return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
+
+
+def fuse_rrf(d_rows, s_rows, limit: int):
+    """Host-only: reciprocal-rank fusion of two ranked row lists (vr_search_hybrid's VR_FUSION_RRF mode alone)."""
+    lib = _lib.load_library()
+    dr, sr = _np(d_rows, np.int64), _np(s_rows, np.int64)
+    cap = max(limit, 1)
+    rows = np.empty(cap, np.int64)
+    scores = np.empty(cap, np.float64)
+    fd = np.empty(cap, np.int32)
+    c = C.c_int32()
+    check(lib.vr_fuse_rrf(_ptr(dr, C.c_int64), dr.shape[0], _ptr(sr, C.c_int64), sr.shape[0], limit,
+                          _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
+    return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
