@@ -53,7 +53,7 @@ typedef struct vr_engine vr_engine;
 typedef struct vr_config {
   int32_t struct_size;   /* = sizeof(vr_config) */
   int32_t device;        /* HIP device ordinal */
-  int32_t dim;           /* dense dimension D (multiple of 16): settings.embedding_dimension, embedding.py:20 */
+  int32_t dim;           /* dense dimension D (multiple of 16, <= 1024): settings.embedding_dimension, embedding.py:20 */
   int32_t flags;         /* VR_ENGINE_* bits */
   int64_t initial_rows;  /* capacity hint; tables grow by doubling */
 } vr_config;
@@ -189,8 +189,9 @@ int vr_bm25_tf(vr_engine* e, const int64_t* tok_off, const int32_t* tok_ids, int
 /* Host-only text side of fastembed's Bm25 (no engine, no GPU): remove_non_alphanumeric,
  * SimpleTokenizer, stop-word / length filter, Snowball English stemmer, abs(murmur3_x86_32)
  * (SURVEY.md a6/a7 [EXT]). texts[i]: lens[i] bytes of UTF-8. out_off: n+1 offsets; out_ids: the
- * hashed stems of every text in order, at most `cap` written; *out_needed: total count (call
- * again with a larger buffer when it exceeds cap). The same stream serves documents
+ * hashed stems of every text in order, at most `cap` written; *out_needed: total count. Returns -2
+ * (offsets and *out_needed valid, the leading `cap` ids written) when the buffer is too small: call
+ * again with one of *out_needed ids. The same stream serves documents
  * (-> vr_bm25_tf) and queries (Bm25.query_embed = the set of these ids, all values 1.0). */
 int vr_bm25_tokenize(const char* const* texts, const int64_t* lens, int64_t n,
                      int64_t* out_off, int32_t* out_ids, int64_t cap, int64_t* out_needed);

@@ -69,7 +69,8 @@ def test_rebuild_matches_a_collection_indexed_with_sparse_vectors(native, tmp_pa
     stats = build_sparse_vectors(batch_size=64, switch=True)
     assert stats["target"] == "voitta_documents_v2" and stats["processed"] == stats["inserted"] == want_count
     assert stats["skipped"] == 0 and stats["rate"] > 0
-    assert all(os.path.exists(index_dir / f"voitta_documents_v2{ext}") for ext in (".vrindex", ".payload.jsonl", ".meta.json"))
+    assert sorted(os.listdir(index_dir)) == ["voitta_documents_v2.g1.payload.jsonl", "voitta_documents_v2.g1.vrindex",
+                                             "voitta_documents_v2.meta.json"]
 
     emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
     assert vs.client.count() == (want_count, want_count)  # tombstones were not copied

@@ -299,3 +299,89 @@ def test_compact_after_reindex_keeps_service_answers(native):
     assert vs.get_collection_info() == info and vs.count_by_file("docs/b.md") == 25
     assert vs.delete_by_file("docs/a.md") == 25 and vs.compact() == 25 and vs.compact() == 0
     assert [c.metadata.chunk_index for c in vs.get_chunks_by_range("docs/c.md", 3, 5)] == [3, 4, 5]
+
+
+def test_save_is_atomic_and_a_damaged_snapshot_is_refused_cleanly(native, tmp_path, monkeypatch):
+    """A crash or a full disk in the middle of save() must leave the LAST GOOD snapshot loadable (the pointer file
+    is the single commit point), and a snapshot whose files do not belong together is refused without leaving a
+    half-bound collection behind: the next call retries from scratch."""
+    import shutil
+
+    path, shape, w, vocab = native()
+    from voitta_rag_amd import config, store_registry, vector_store
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.vector_store import ChunkMetadata, VectorStoreService
+
+    rng = np.random.default_rng(12)
+    emb = get_embedding_service()
+    vs = VectorStoreService()
+    texts = _texts(rng, 30)
+    metas = [ChunkMetadata(file_path=f"docs/f{i % 3}.md", folder_path="docs", index_folder="docs", file_name=f"f{i % 3}.md",
+                           chunk_index=i // 3, total_chunks=10, start_char=0, end_char=9, indexed_at="t") for i in range(30)]
+    vectors = emb.embed_texts(texts)
+    vs.store_chunks(list(zip(texts[:20], vectors[:20], metas[:20])))
+    q = vectors[3]
+    index_dir = str(tmp_path / "persist")
+    vs.save(index_dir)
+    want = [(c.id, c.score) for c in vs.search(q, limit=5)]
+    first_files = sorted(os.listdir(index_dir))
+    assert first_files == ["voitta_documents.g1.payload.jsonl", "voitta_documents.g1.vrindex", "voitta_documents.meta.json"]
+
+    # ---- a save that dies before its commit point (here: while writing the pointer file)
+    vs.store_chunks(list(zip(texts[20:], vectors[20:], metas[20:])))
+    real = VectorStoreService._write_durably
+
+    def dying(path_, write):
+        if path_.endswith(".meta.json"):
+            raise OSError(28, "No space left on device")
+        return real(path_, write)
+
+    monkeypatch.setattr(VectorStoreService, "_write_durably", staticmethod(dying))
+    with pytest.raises(OSError):
+        vs.save(index_dir)
+    monkeypatch.setattr(VectorStoreService, "_write_durably", staticmethod(real))
+    assert set(first_files) <= set(os.listdir(index_dir))  # generation 1 is untouched
+
+    def restart():
+        monkeypatch.setenv("VOITTA_INDEX_DIR", index_dir)
+        config.get_settings.cache_clear()
+        store_registry.reset()
+        vector_store._vector_store = None
+        return VectorStoreService()
+
+    vs2 = restart()
+    assert vs2.get_collection_info()["points_count"] == 20  # the last GOOD snapshot, not a mixture
+    assert [(c.id, c.score) for c in vs2.search(q, limit=5)] == want
+
+    # ---- a completed second save replaces generation 1 and removes it
+    vs2.store_chunks(list(zip(texts[20:], vectors[20:], metas[20:])))
+    vs2.save(index_dir)
+    assert sorted(os.listdir(index_dir)) == ["voitta_documents.g2.payload.jsonl", "voitta_documents.g2.vrindex",
+                                             "voitta_documents.meta.json"]
+    assert restart().get_collection_info()["points_count"] == 30
+
+    # ---- damaged snapshots: refused, nothing half-bound stays behind, a repaired snapshot loads on retry
+    payload = os.path.join(index_dir, "voitta_documents.g2.payload.jsonl")
+    index = os.path.join(index_dir, "voitta_documents.g2.vrindex")
+    shutil.copy(payload, payload + ".keep")
+    shutil.copy(index, index + ".keep")
+    for damage in ("truncate", "missing", "foreign-index"):
+        if damage == "truncate":
+            lines = open(payload, encoding="utf-8").read().splitlines(True)
+            open(payload, "w", encoding="utf-8").writelines(lines[:10])
+        elif damage == "missing":
+            os.remove(payload)
+        else:
+            blob = bytearray(open(index, "rb").read())
+            blob[40] ^= 0xFF  # a header field: no longer the file this generation was saved with
+            open(index, "wb").write(bytes(blob))
+        vs3 = restart()
+        with pytest.raises((ValueError, FileNotFoundError, RuntimeError)):
+            vs3.search(q, limit=5)
+        assert vs3._client is None  # not half-bound ...
+        with pytest.raises((ValueError, FileNotFoundError, RuntimeError)):
+            vs3.search(q, limit=5)  # ... so a second call fails the same way instead of serving an empty collection
+        assert store_registry.get_engine().count() == (0, 0)
+        shutil.copy(payload + ".keep", payload)
+        shutil.copy(index + ".keep", index)
+        assert len(vs3.search(q, limit=5)) == 5  # repaired: the same object recovers without a restart

@@ -21,10 +21,14 @@ def hashed_stems(texts: list[str]) -> tuple[np.ndarray, np.ndarray]:
     off = np.zeros(n + 1, np.int64)
     ids = np.zeros(max(cap, 1), np.int32)
     need = C.c_int64()
-    check(lib.vr_bm25_tokenize(arr, lens.ctypes.data_as(C.POINTER(C.c_int64)), n,
-                               off.ctypes.data_as(C.POINTER(C.c_int64)), ids.ctypes.data_as(C.POINTER(C.c_int32)),
-                               cap, C.byref(need)))
-    assert need.value <= cap
+    for _ in range(2):
+        rc = lib.vr_bm25_tokenize(arr, lens.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                                  off.ctypes.data_as(C.POINTER(C.c_int64)), ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  ids.shape[0], C.byref(need))
+        if rc != -2:
+            break
+        ids = np.zeros(need.value, np.int32)  # (cannot happen with the bound above; the ABI allows it)
+    check(rc)
     return off, ids[: need.value].copy()
 
 

@@ -138,7 +138,8 @@ const char* vr_last_error(void) { return g_last_error.c_str(); }
 int vr_engine_create(const vr_config* cfg, vr_engine** out) {
   VR_CHECK(cfg && out, "null argument");
   VR_CHECK(cfg->struct_size == static_cast<int32_t>(sizeof(vr_config)), "vr_config size mismatch");
-  VR_CHECK(cfg->dim > 0 && cfg->dim % 16 == 0, "dim %d must be a positive multiple of 16", cfg->dim);
+  VR_CHECK(cfg->dim > 0 && cfg->dim % 16 == 0 && cfg->dim <= kMaxDim, "dim %d must be a multiple of 16 in 16..%d",
+           cfg->dim, kMaxDim);
   int n_dev = 0;
   hipError_t err = hipGetDeviceCount(&n_dev);
   VR_CHECK(err == hipSuccess && n_dev > 0,

@@ -364,6 +364,10 @@ int vr_bm25_tokenize(const char* const* texts, const int64_t* lens, int64_t n, i
     out_off[i + 1] = total;
   }
   *out_needed = total;
+  if (total > cap) {  // offsets and *out_needed are valid; call again with a buffer of that many ids
+    vr::set_error("vr_bm25_tokenize: %lld ids, buffer holds %lld", static_cast<long long>(total), static_cast<long long>(cap));
+    return -2;
+  }
   return 0;
 }
 

@@ -1080,6 +1080,17 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #undef VR_GLDS_STAGE
 }
 
+// Diagnostic build only (make diag -> libvoitta_engine_diag.so, selected with VOITTA_ENGINE_LIB): VR_GEMM_DIAG in the
+// environment switches parts of gemm_f16_pp_kernel off at run time, so that one box can time the kernel without
+// its loads (1), its epilogue (2), its MFMAs (4), its fragment reads (8) or its barriers (16). Results are then
+// wrong by construction; only the timings mean anything. The shipped library compiles none of this.
+#ifdef VR_GEMM_DIAG_BUILD
+__device__ int g_gemm_diag = 0;
+#define VR_DIAG(bit) ((diag_bits & (bit)) != 0)
+#else
+#define VR_DIAG(bit) false
+#endif
+
 // ---- the 256x256 f16 product with a ping-pong main loop ----------------------------------------------
 //
 // Same tile, LDS image, swizzle, persistent tile walk and epilogues as gemm_f16x3_256_kernel<EPI, 1>; what
@@ -1097,19 +1108,10 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 //     vmcnt two to three phases after its issue (never vmcnt(0) in the loop) — two half-tiles stay in flight
 //     across every barrier. A wait sits in the READ segment of the phase BEFORE the one that reads the data, so
 //     that every wave's wait and one more barrier lie between a load and any wave's read of it.
+//   * the MFMAs take the WEIGHT fragment as their A operand, which leaves every lane with four consecutive
+//     output features of one token: the epilogue stores straight from the accumulators (no LDS transpose).
 // Accumulation order per output element is unchanged (k ascending), so the result is bit-identical to
-// gemm_f16x3_256_kernel<EPI, 1>. Needs an even number of K-tiles (K % 128 == 0: every supported width).
-// Diagnostic build only (make diag -> libvoitta_engine_diag.so, selected with VOITTA_ENGINE_LIB): VR_GEMM_DIAG in the
-// environment switches parts of gemm_f16_pp_kernel off at run time, so that one box can time the kernel without
-// its loads (1), its epilogue (2), its MFMAs (4), its fragment reads (8) or its barriers (16). Results are then
-// wrong by construction; only the timings mean anything. The shipped library compiles none of this.
-#ifdef VR_GEMM_DIAG_BUILD
-__device__ int g_gemm_diag = 0;
-#define VR_DIAG(bit) ((diag_bits & (bit)) != 0)
-#else
-#define VR_DIAG(bit) false
-#endif
-
+// gemm_f16x3_256_kernel<EPI, 1>. Needs an even number of K-tiles (K % 128 == 0) and N % 8 == 0: every supported width.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Wh, const float* __restrict__ bias,
@@ -1148,17 +1150,21 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int srow = lane >> 3;
   const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
   const int ra = wave * 8 + srow;
-  const int rw = 64 * (wave >> 2) + 8 * (wave & 3) + srow;
+  // image rows 64 (w >> 2) + 8 (w & 3) + srow (+ 0, 128, 32, 160): q = (w >> 1) & 1, r = 8 (w & 1) + srow of the
+  // permutation above, i.e. weight row 64 (w >> 2) + 16 (w & 1) + 8 (srow >> 2) + 4 ((w >> 1) & 1) + (srow & 3)
+  const int rwp = 64 * (wave >> 2) + 16 * (wave & 1) + 8 * (srow >> 2) + 4 * ((wave >> 1) & 1) + (srow & 3);
   const half_t *g_a0, *g_a1, *g_a2, *g_a3, *g_w0, *g_w1, *g_w2, *g_w3;
   auto set_ptrs = [&](int bm_, int bn_) {
     g_a0 = Ah + static_cast<int64_t>(min(bm_ + ra, M - 1)) * K + schunk;        // lo
     g_a1 = Ah + static_cast<int64_t>(min(bm_ + ra + 128, M - 1)) * K + schunk;  // lo
     g_a2 = Ah + static_cast<int64_t>(min(bm_ + ra + 64, M - 1)) * K + schunk;   // hi
     g_a3 = Ah + static_cast<int64_t>(min(bm_ + ra + 192, M - 1)) * K + schunk;  // hi
-    g_w0 = Wh + static_cast<int64_t>(min(bn_ + rw, N - 1)) * K + schunk;        // lo
-    g_w1 = Wh + static_cast<int64_t>(min(bn_ + rw + 128, N - 1)) * K + schunk;  // lo
-    g_w2 = Wh + static_cast<int64_t>(min(bn_ + rw + 32, N - 1)) * K + schunk;   // hi
-    g_w3 = Wh + static_cast<int64_t>(min(bn_ + rw + 160, N - 1)) * K + schunk;  // hi
+    // W rows are staged PERMUTED inside every block of 32: image row 32 P + 16 q + r holds weight row
+    // 32 P + 8 (r >> 2) + 4 q + (r & 3) — see the epilogue: a lane then owns 8 consecutive output features
+    g_w0 = Wh + static_cast<int64_t>(min(bn_ + rwp, N - 1)) * K + schunk;        // lo
+    g_w1 = Wh + static_cast<int64_t>(min(bn_ + rwp + 128, N - 1)) * K + schunk;  // lo
+    g_w2 = Wh + static_cast<int64_t>(min(bn_ + rwp + 32, N - 1)) * K + schunk;   // hi
+    g_w3 = Wh + static_cast<int64_t>(min(bn_ + rwp + 160, N - 1)) * K + schunk;  // hi
   };
   set_ptrs(bm, bn);
   // wave-uniform LDS destinations (halfs, inside a stage buffer)
@@ -1253,7 +1259,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 1: rows 0-63 x columns 32-63 ---------------------------------------------------------
@@ -1273,7 +1279,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[i][2 + j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[i][2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 2: rows 64-127 x columns 32-63 -------------------------------------------------------
@@ -1292,7 +1298,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[4 + i][2 + j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[4 + i][2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 3: rows 64-127 x columns 0-31 (W fragments read again: holding them costs 16 VGPRs) ----
@@ -1312,7 +1318,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[4 + i][j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[4 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
     };
@@ -1322,123 +1328,126 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       ktile(std::integral_constant<int, 1>{}, kt + 1);
     }
 
-    // Epilogue (as gemm_f16x3_256_kernel): through this wave's own region of stage buffer 1 — the buffer of
-    // the last K-tile, free now; the next tile's K-tile 0 sits in buffer 0. W hi / A hi of that K-tile may
-    // still be in flight: they are waited for HERE, before this wave's stores queue up behind them (vmcnt
-    // retires in order: a counted wait in the next main loop would otherwise wait for the stores too).
+    // waves 0-3 are a segment ahead: they wait here for waves 4-7's last MFMA segment, so that all eight waves
+    // run the epilogue TOGETHER (bracketed by barriers it would run once per half, one after the other)
+    if (wm == 0) VR_PP_BARRIER();
+    // Epilogue, straight from the accumulators. The MFMAs ran with the WEIGHT fragment as the A operand, so
+    // acc[i][j][r] of lane (t = lane & 15, g = lane >> 4) is token row 16 i + t, feature 4 g + r of weight
+    // fragment j — four CONSECUTIVE features of one token — and the W image was staged with its rows permuted
+    // (see set_ptrs) so that fragments 2p and 2p + 1 hold features 32 p + 8 g + {0..3} and {4..7}: a lane owns 8
+    // consecutive features per fragment pair = one 16-byte f16 store (or two 16-byte f32 stores), 64 contiguous
+    // bytes per token and instruction across the four lane groups. No transpose through LDS (it cost 128
+    // ds_write_b32 + 32 ds_read_b128 per wave and tile, about half of the f16-output epilogue) and no LDS use at
+    // all, so the next tile's loads may land while this runs.
+    // W hi / A hi of the next tile's K-tile 0 may still be in flight: waited for HERE, before this wave's
+    // stores queue up behind them (vmcnt retires in order: a counted wait in the next main loop would otherwise
+    // wait for the stores too).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!VR_DIAG(2)) {
-    constexpr int SLD = 64 + 4;
-    float* stage = reinterpret_cast<float*>(lds) + (kStageHalfs / 2) + wave * (16 * SLD);
-    const int c4 = (lane & 15) * 4;
-    const int gcol = bn + wn * 64 + c4;
-    const bool col_ok = gcol < N;
-    const float4 b4 = *reinterpret_cast<const float4*>(bias + (col_ok ? gcol : 0));
+    const int tok = lane & 15, fg = lane >> 4;
+    const int fbase = bn + wn * 64 + 8 * fg;  // + 32 p (+ 4 q): this lane's features
     constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
     constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS;
     constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
     constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
-    float4 lg4 = make_float4(0.f, 0.f, 0.f, 0.f), lb4 = lg4;
-    if (kResidLN || kFold) lg4 = *reinterpret_cast<const float4*>(ln_g + (col_ok ? gcol : 0));
-    if (kResidLN) lb4 = *reinterpret_cast<const float4*>(ln_b + (col_ok ? gcol : 0));
-    float4 r4[2][4];
-    float2 st4[2][4];
-    auto fetch_residual = [&](int pc, float4 (&r)[4], float2 (&st)[4]) {
+    constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
+    constexpr bool kHalfOut = kGelu || EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16;
+    float s1[8], s2[8];  // kStats: this lane's share of the row sums, per piece
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int64_t rr = min(bm + wm * 128 + 16 * pc + (lane >> 4) + 4 * it, M - 1);
-        if (kResidual) r[it] = *reinterpret_cast<const float4*>(R + rr * N + (col_ok ? gcol : 0));
-        if (kResidLN || kFold) st[it] = ln_stat[rr];
+    for (int pc = 0; pc < 8; ++pc) s1[pc] = s2[pc] = 0.0f;
+    // fragment pair p2 (features fbase + 32 p2 .. + 7) outside, the eight 16-token pieces inside: the column
+    // vectors (bias, LayerNorm gain / shift or column sums) of one pair stay in registers, not those of all four
+    // fragments (which, with the residual rows in flight, did not fit next to the 128 accumulators)
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int c0 = fbase + 32 * p2;
+      const bool col_ok = c0 < N;  // N % 8 == 0: a lane's eight features are in or out together
+      const int cs = col_ok ? c0 : 0;
+      float4 b4[2], lg4[2] = {}, lb4[2] = {};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        b4[q] = *reinterpret_cast<const float4*>(bias + cs + 4 * q);
+        if (kResidLN || kFold) lg4[q] = *reinterpret_cast<const float4*>(ln_g + cs + 4 * q);
+        if (kResidLN) lb4[q] = *reinterpret_cast<const float4*>(ln_b + cs + 4 * q);
       }
-    };
-    if (kResidual || kFold) fetch_residual(0, r4[0], st4[0]);
-#pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
-      const int row0 = bm + wm * 128 + 16 * pc + (lane >> 4);
-      if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st4[(pc + 1) & 1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stage[(4 * (lane >> 4) + r) * SLD + j * 16 + (lane & 15)] = acc[pc][j][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      auto emit = [&](int it) {
-        const int lr = it * 4 + (lane >> 4);
-        const int grow = row0 + 4 * it;
-        float4 v = *reinterpret_cast<const float4*>(stage + lr * SLD + c4);
-        const bool ok = grow < M && col_ok;
-        if (!kStats && !ok) return;
-        if (kFold) {
-          const float2 st = st4[pc & 1][it];
-          v.x = fmaf(fmaf(v.x, unscale, -(st.x * lg4.x)), st.y, b4.x);
-          v.y = fmaf(fmaf(v.y, unscale, -(st.x * lg4.y)), st.y, b4.y);
-          v.z = fmaf(fmaf(v.z, unscale, -(st.x * lg4.z)), st.y, b4.z);
-          v.w = fmaf(fmaf(v.w, unscale, -(st.x * lg4.w)), st.y, b4.w);
-        } else {
-          v.x = v.x * unscale + b4.x;
-          v.y = v.y * unscale + b4.y;
-          v.z = v.z * unscale + b4.z;
-          v.w = v.w * unscale + b4.w;
+      // residual rows (and row statistics) of a piece are requested one piece ahead
+      float4 r4[2][2] = {};
+      float2 st2[2] = {};
+      auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
+        const int64_t rr = min(bm + wm * 128 + 16 * pc + tok, M - 1);
+        if (kResidual) {
+          r[0] = *reinterpret_cast<const float4*>(R + rr * N + cs);
+          r[1] = *reinterpret_cast<const float4*>(R + rr * N + cs + 4);
         }
-        const int64_t o = static_cast<int64_t>(grow) * N + gcol;
-        if (EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU) {
-          const f32x2 g01 = gelu_poly2(f32x2{v.x, v.y});
-          const f32x2 g23 = gelu_poly2(f32x2{v.z, v.w});
-          float g[4] = {g01.x, g01.y, g23.x, g23.y};
-          half_t h[4], l[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) split_f16(g[c], h[c], l[c]);
-          *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
-        } else if (EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16) {
-          half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
-                         static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
-                         static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
-                         static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
-          *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
-        } else {
-          if (EPI == EPI_BIAS_RESIDUAL) {
-            v.x += r4[pc & 1][it].x;
-            v.y += r4[pc & 1][it].y;
-            v.z += r4[pc & 1][it].z;
-            v.w += r4[pc & 1][it].w;
-          }
-          if (kResidLN) {
-            const float2 st = st4[pc & 1][it];
-            v.x += ln_apply(r4[pc & 1][it].x, st.x, st.y, lg4.x, lb4.x);
-            v.y += ln_apply(r4[pc & 1][it].y, st.x, st.y, lg4.y, lb4.y);
-            v.z += ln_apply(r4[pc & 1][it].z, st.x, st.y, lg4.z, lb4.z);
-            v.w += ln_apply(r4[pc & 1][it].w, st.x, st.y, lg4.w, lb4.w);
-          }
-          if (!kStats) {
-            *reinterpret_cast<float4*>(C + o) = v;
-          } else {
-            float s1 = 0.0f, s2 = 0.0f;
-            if (ok) {
-              *reinterpret_cast<float4*>(C + o) = v;
-              half_t h[4] = {static_cast<half_t>(fminf(fmaxf(v.x, -65504.0f), 65504.0f)),
-                             static_cast<half_t>(fminf(fmaxf(v.y, -65504.0f), 65504.0f)),
-                             static_cast<half_t>(fminf(fmaxf(v.z, -65504.0f), 65504.0f)),
-                             static_cast<half_t>(fminf(fmaxf(v.w, -65504.0f), 65504.0f))};
-              *reinterpret_cast<uint2*>(Ch + o) = *reinterpret_cast<const uint2*>(h);
-              s1 = (v.x + v.y) + (v.z + v.w);
-              s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-              s1 += __shfl_xor(s1, off);
-              s2 += __shfl_xor(s2, off);
-            }
-            const int seg = (bn + wn * 64) >> 6;
-            if ((lane & 15) == 0 && grow < M && seg < (N >> 6))
-              reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(s1, s2);
-          }
-        }
+        if (kResidLN || kFold) st = ln_stat[rr];
       };
+      if (kResidual || kFold) fetch_residual(0, r4[0], st2[0]);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) emit(it);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
+        const int grow = bm + wm * 128 + 16 * pc + tok;
+        if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
+        const bool ok = grow < M && col_ok;
+        const float2 st = st2[pc & 1];
+        float v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+          const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
+          const float lb[4] = {lb4[q].x, lb4[q].y, lb4[q].z, lb4[q].w};
+          const float4 rq = r4[pc & 1][q];
+          const float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[pc][2 * p2 + q][r];
+            if (kFold)  // inv (acc unscale - mean colsum) + c
+              x = fmaf(fmaf(x, unscale, -(st.x * gg[r])), st.y, bb[r]);
+            else
+              x = x * unscale + bb[r];
+            if (EPI == EPI_BIAS_RESIDUAL) x += rr4[r];
+            if (kResidLN) x += ln_apply(rr4[r], st.x, st.y, gg[r], lb[r]);  // residual = LayerNorm(R row)
+            v[q][r] = x;
+          }
+          if (kGelu) {
+            const f32x2 g01 = gelu_poly2(f32x2{v[q][0], v[q][1]});
+            const f32x2 g23 = gelu_poly2(f32x2{v[q][2], v[q][3]});
+            v[q][0] = g01.x, v[q][1] = g01.y, v[q][2] = g23.x, v[q][3] = g23.y;
+          }
+        }
+        if (kHalfOut || kStats) {  // f16 row: 8 consecutive features, one 16-byte store
+          f16x8 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = static_cast<half_t>(fminf(fmaxf(v[0][r], -65504.0f), 65504.0f));
+            h[4 + r] = static_cast<half_t>(fminf(fmaxf(v[1][r], -65504.0f), 65504.0f));
+          }
+          if (ok) *reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow) * N + c0) = h;
+        }
+        if (!kHalfOut && ok) {  // f32 row
+          *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0 + 4) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+        }
+        if (kStats && col_ok) {
+          s1[pc] += ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+          s2[pc] += ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
+                    ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
+        }
+      }
+    }
+    if (kStats) {
+      // this wave's 64 columns of every pre-LayerNorm row contribute a (sum, sum of squares) to the row's
+      // statistics: 16 values per lane (summed above), the other 48 in the three other lane groups
+      const int seg = (bn + wn * 64) >> 6;
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        float a1 = s1[pc], a2 = s2[pc];
+        a1 += __shfl_xor(a1, 16);
+        a2 += __shfl_xor(a2, 16);
+        a1 += __shfl_xor(a1, 32);
+        a2 += __shfl_xor(a2, 32);
+        const int grow = bm + wm * 128 + 16 * pc + tok;
+        if (fg == 0 && grow < M && seg < (N >> 6))
+          reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(a1, a2);
+      }
     }
     } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
       float t = 0.0f;
@@ -1450,12 +1459,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     tile = next;
     bm = nbm;
     bn = nbn;
-    // every wave has left the staging region (buffer 1) before any wave's first load of the next tile's
-    // K-tile 1 lands in it: waves 0-3 run a segment ahead, so TWO barriers separate the two
     VR_PP_BARRIER();
-    VR_PP_BARRIER();
+    if (wm == 1) VR_PP_BARRIER();  // waves 4-7 fall one segment behind again
   }  // tiles
-  if (wm == 0) VR_PP_BARRIER();  // pairs with the extra barrier waves 4-7 took at the start
 #undef VR_PP_BARRIER
 #undef VR_PP_VMCNT4
 }
@@ -1933,7 +1939,7 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
     const int grid256 = std::min(tiles, n_cu);
     // f16 mode: the ping-pong main loop (gemm_f16_pp_kernel); VR_GEMM_PP=0 keeps the one-barrier-per-K-tile loop
     static const bool pp_on = !(getenv("VR_GEMM_PP") && atoi(getenv("VR_GEMM_PP")) == 0);
-    if (passes == 1 && pp_on && K % 128 == 0)
+    if (passes == 1 && pp_on && K % 128 == 0 && N % 8 == 0)
       launch_pp(epi, grid256, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
     else if (passes == 1)
       launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);

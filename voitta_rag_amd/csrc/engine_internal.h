@@ -84,21 +84,27 @@ struct SliceDesc {
 constexpr int kTileRows = 16;      // corpus rows per MFMA tile (v_mfma_f32_16x16x4_f32 M)
 constexpr int kTileK = 16;         // k elements per 1-KiB tile block
 constexpr int kTopkSeg = 4096;     // keys per block in the first select level
-constexpr int kMaxK = 256;         // largest top-k a search may ask for
+constexpr int kMaxK = 1024;        // largest top-k a search may ask for (hybrid: 3 * limit, so limit <= 341)
 constexpr int kQueryBlock = 16;    // queries per dense pass (MFMA N)
 constexpr int kScanBlocks = 512;   // grid of the fused scan+select kernels: 2 blocks per CU, and
                                    // 512 candidate lists per query for merge_lists_kernel
 constexpr int kFusedMaxK = 64;     // fused selection keeps lists of 64 (one entry per lane)
-constexpr int kMaxQueryTerms = 256;  // distinct terms of one sparse query
+constexpr int kMaxQueryTerms = 1024;  // distinct terms of one sparse query
+constexpr int kMaxDim = 1024;         // dense dimension (the pinned query block below holds 16 x kMaxDim floats)
 
 // layout of the pinned scratch
 constexpr size_t kPinSparseIds = 0;            // int32[kMaxQueryTerms]
-constexpr size_t kPinSparseVals = 1024;        // float[kMaxQueryTerms]
-constexpr size_t kPinQuery = 8192;             // float[16][dim <= 1024]
-constexpr size_t kPinDenseKeys = 128 * 1024;   // uint64[16][kMaxK]
-constexpr size_t kPinSparseKeys = 192 * 1024;  // uint64[kMaxK]
-constexpr size_t kPinCandCount = 256 * 1024;   // int32: candidates of the last two-stage dense search
+constexpr size_t kPinSparseVals = 4096;        // float[kMaxQueryTerms]
+constexpr size_t kPinQuery = 8192;             // float[kQueryBlock][dim <= kMaxDim]
+constexpr size_t kPinDenseKeys = 128 * 1024;   // uint64[kQueryBlock][kMaxK]
+constexpr size_t kPinSparseKeys = 256 * 1024;  // uint64[kMaxK]
+constexpr size_t kPinCandCount = 272 * 1024;   // int32: candidates of the last two-stage dense search
 constexpr size_t kPinnedBytes = 1 << 20;
+static_assert(kPinSparseVals >= kPinSparseIds + sizeof(int32_t) * kMaxQueryTerms, "pinned layout");
+static_assert(kPinQuery >= kPinSparseVals + sizeof(float) * kMaxQueryTerms, "pinned layout");
+static_assert(kPinDenseKeys >= kPinQuery + sizeof(float) * kQueryBlock * kMaxDim, "pinned layout");
+static_assert(kPinSparseKeys >= kPinDenseKeys + sizeof(uint64_t) * kQueryBlock * kMaxK, "pinned layout");
+static_assert(kPinCandCount >= kPinSparseKeys + sizeof(uint64_t) * kMaxK && kPinCandCount + 64 <= kPinnedBytes, "pinned layout");
 // re-score budget of the two-stage dense search: candidate TILES (16 rows, one tile read each: at most
 // 16384 x 48 KiB = 0.8 GB at D = 768, a quarter of the one-stage scan it replaces). The candidate-row count
 // the device reports is at most kMaxCandidates, or INT32_MAX when the tile budget overflowed.

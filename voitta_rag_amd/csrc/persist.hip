@@ -11,6 +11,9 @@
 
 #include "engine_internal.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <string>
 
@@ -164,10 +167,21 @@ int engine_save(vr_engine* e, const char* path) {
   h.payload_bytes = io.bytes;
   h.checksum = io.sum;
   VR_CHECK(fseek(io.f, 0, SEEK_SET) == 0 && fwrite(&h, 1, sizeof(h), io.f) == sizeof(h), "cannot finish %s", tmp.c_str());
-  VR_CHECK(fflush(io.f) == 0, "flush failed");
-  fclose(io.f);
+  // durable before it becomes visible: data to disk, then the rename, then the directory entry
+  VR_CHECK(fflush(io.f) == 0 && fsync(fileno(io.f)) == 0, "flush of %s failed", tmp.c_str());
+  VR_CHECK(fclose(io.f) == 0, "closing %s failed", tmp.c_str());
   io.f = nullptr;
   VR_CHECK(rename(tmp.c_str(), path) == 0, "cannot rename %s to %s", tmp.c_str(), path);  // atomic replace
+  {
+    std::string dir(path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? "." : (slash == 0 ? "/" : dir.substr(0, slash));
+    const int dfd = open(dir.c_str(), O_RDONLY | O_DIRECTORY);
+    if (dfd >= 0) {
+      (void)fsync(dfd);
+      close(dfd);
+    }
+  }
   return 0;
 }
 

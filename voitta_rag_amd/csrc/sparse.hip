@@ -239,11 +239,11 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
 
 // ---- query ------------------------------------------------------------------------------------
 
-constexpr int kQHash = 1024;   // LDS hash slots for the query terms
+constexpr int kQHash = 4096;   // LDS hash slots for the query terms (4 x kMaxQueryTerms)
 constexpr int kSparseWaves = 16;  // 1024-thread blocks: 2 per CU = every wave slot busy (the scan
                                   // is a latency-bound gather; it wants all the loads in flight)
 
-// One kernel per sparse query. Prologue (every block, redundantly): read the <=256 sorted query
+// One kernel per sparse query. Prologue (every block, redundantly): read the <= kMaxQueryTerms sorted query
 // terms straight from the pinned host scratch, weight them — q_t * idf_t with idf from the
 // document-frequency table, or as given — and build an LDS hash. Body: SELL-64 scan, one row per
 // lane, ascending-id accumulation. FUSED keeps the k best (score, row) keys per wave
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kSparseWaves * 64) void sparse_scores_kernel(
     t_w[threadIdx.x] = w;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {  // <= 256 terms; serial insert keeps the table deterministic
+  if (threadIdx.x == 0) {  // a handful of terms (<= kMaxQueryTerms); serial insert keeps the table deterministic
     for (int t = 0; t < nnz; ++t) {
       const int32_t id = t_id[t];
       uint32_t h = df_hash(id) & (kQHash - 1);

@@ -69,6 +69,19 @@ def tensor_names(layers: int) -> list[str]:
     return names
 
 
+def expected_shape(desc: BertDesc, name: str) -> tuple:
+    """Shape of a state-dict entry as the description implies it ([out, in] layout, as HF stores it)."""
+    H, inter = desc.hidden, desc.intermediate
+    if name.endswith("word_embeddings.weight"): return (desc.vocab, H)
+    if name.endswith("position_embeddings.weight"): return (desc.max_pos, H)
+    if name.endswith("token_type_embeddings.weight"): return (desc.type_vocab, H)
+    if name.endswith("intermediate.dense.weight"): return (inter, H)
+    if name.endswith("intermediate.dense.bias"): return (inter,)
+    if name.endswith("output.dense.weight") and "attention" not in name: return (H, inter)
+    if name.endswith(".weight") and "LayerNorm" not in name: return (H, H)
+    return (H,)
+
+
 def _find(state: dict, suffix: str):
     if suffix in state:
         return state[suffix]
@@ -81,7 +94,14 @@ def _find(state: dict, suffix: str):
 def load_encoder(engine, desc: BertDesc, state: dict) -> None:
     """state: HF BertModel state dict (any key prefix), values NumPy arrays or torch tensors.
     Tensors on the engine's GPU are passed as device pointers, everything else as host memory."""
-    tensors = [_find(state, n) for n in tensor_names(desc.layers)]
+    names = tensor_names(desc.layers)
+    tensors = [_find(state, n) for n in names]
+    # raw pointers cross the C-ABI next: a checkpoint whose config.json disagrees with its weights (padded or
+    # resized vocabulary, another max_position_embeddings, ...) must fail HERE, not read past a buffer there
+    for name, t in zip(names, tensors):
+        want = expected_shape(desc, name)
+        if tuple(t.shape) != want:
+            raise ValueError(f"weight '{name}' has shape {tuple(t.shape)}, the model description implies {want}")
     on_device = all(hasattr(t, "is_cuda") and t.is_cuda for t in tensors)
     keep, ptrs = [], []
     for t in tensors:

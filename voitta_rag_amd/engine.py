@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -348,20 +349,25 @@ class Engine:
             mem, qp = VR_MEM_HOST, C.c_void_p(q.ctypes.data)
         qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
         # latency path: output buffers and their addresses are kept per `limit`, and the call goes through a
-        # prototype that takes plain addresses (building five ctypes POINTER objects per query cost ~10 us)
-        slot = self._hybrid_slots.get(limit) if hasattr(self, "_hybrid_slots") else None
+        # prototype that takes plain addresses (building five ctypes POINTER objects per query cost ~10 us).
+        # The buffers are PER THREAD: the engine call drops the GIL and an engine may be called from any number
+        # of threads (include/voitta_engine.h), so a shared set could be overwritten before it is copied out.
+        if not hasattr(self, "_hybrid_fn"):
+            fn = self._lib["vr_search_hybrid"]
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double,
+                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            self._hybrid_fn = fn
+            self._hybrid_tls = threading.local()
+        slots = getattr(self._hybrid_tls, "slots", None)
+        if slots is None:
+            slots = self._hybrid_tls.slots = {}
+        slot = slots.get(limit)
         if slot is None:
-            if not hasattr(self, "_hybrid_slots"):
-                self._hybrid_slots = {}
-                fn = self._lib["vr_search_hybrid"]
-                fn.restype = C.c_int
-                fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double,
-                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-                self._hybrid_fn = fn
             rows, scores, fd = np.empty(limit, np.int64), np.empty(limit, np.float64), np.empty(limit, np.int32)
             cnt = np.zeros(1, np.int32)
             slot = (rows, scores, fd, cnt, rows.ctypes.data, scores.ctypes.data, fd.ctypes.data, cnt.ctypes.data)
-            self._hybrid_slots[limit] = slot
+            slots[limit] = slot
         rows, scores, fd, cnt, rp, sp, fdp, cp = slot
         if flt is None or flt.is_empty():
             fptr, keep = None, None

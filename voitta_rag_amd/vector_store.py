@@ -22,6 +22,7 @@ from .config import get_settings
 from .engine import VR_TS_ABSENT, SearchFilter
 from .sparse_embedding import SPARSE_VECTOR_NAME  # noqa: F401  (re-exported like the reference)
 from .store_registry import collection, get_engine
+from .store_registry import forget as forget_collection
 
 logger = logging.getLogger(__name__)
 
@@ -110,7 +111,15 @@ class VectorStoreService:
         if self._client is None:
             logger.info("Binding collection '%s' to the native engine", self.collection_name)
             self._client = get_engine()
-            self._ensure_collection()
+            try:
+                self._ensure_collection()
+            except Exception:
+                # a saved index that cannot be loaded: nothing half-bound may stay behind (the engine commits a
+                # load only when its checksum held, the host table is installed last), so the next call retries
+                # from scratch instead of finding a registered-but-empty collection
+                self._client = None
+                forget_collection(self.collection_name)
+                raise
         return self._client
 
     def _ensure_collection(self) -> None:
@@ -125,7 +134,7 @@ class VectorStoreService:
 
         col = collection(self.collection_name, factory)
         index_dir = get_settings().index_dir
-        if fresh and index_dir and os.path.exists(self._paths(index_dir)[0]) and self._client.count()[0] == 0:
+        if fresh and index_dir and self.has_saved(index_dir) and self._client.count()[0] == 0:
             self._load_into(col, index_dir)
         self._has_sparse = True  # every collection is created with the "bm25" sparse vector (:95-99,114)
 
@@ -155,31 +164,97 @@ class VectorStoreService:
             return dead
 
     # ---- persistence ---------------------------------------------------------
-    def _paths(self, directory: str) -> tuple[str, str, str]:
+    # On disk a collection is ONE small pointer file, ``<name>.meta.json``, plus the two data files of the
+    # generation it names: ``<name>.g<G>.vrindex`` (the device image, Engine.save) and
+    # ``<name>.g<G>.payload.jsonl`` (a header line, then one JSON line per row: point id + payload, ``null``
+    # for deleted rows). save() writes a NEW generation's data files completely (tmp, fsync, rename), and only
+    # then replaces the pointer file (tmp, fsync, rename, directory fsync): the rename of the pointer is the
+    # single commit point. A crash or a full disk before it leaves the previous generation untouched and
+    # loadable; after it the previous generation's files are deleted. The pointer also records the size and a
+    # digest of the index file's header (which holds the checksum of its content) and the payload header repeats
+    # the generation, so a load can tell files that do not belong together.
+    def _paths(self, directory: str, generation: int | None = None) -> tuple[str, str, str]:
         base = os.path.join(directory, self.collection_name)
-        return base + ".vrindex", base + ".payload.jsonl", base + ".meta.json"
+        if generation is None:  # format 1 (one fixed name per file), still readable
+            return base + ".vrindex", base + ".payload.jsonl", base + ".meta.json"
+        return f"{base}.g{generation}.vrindex", f"{base}.g{generation}.payload.jsonl", base + ".meta.json"
+
+    @staticmethod
+    def _fsync_dir(directory: str) -> None:
+        fd = os.open(directory, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+
+    @staticmethod
+    def _write_durably(path: str, write) -> None:
+        with open(path + ".tmp", "w", encoding="utf-8") as f:
+            write(f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(path + ".tmp", path)
+
+    @staticmethod
+    def _index_digest(index_path: str) -> tuple[int, str]:
+        import hashlib
+
+        with open(index_path, "rb") as f:
+            head = f.read(96)  # FileHeader of csrc/persist.hip: row counts + checksum of everything behind it
+        return os.path.getsize(index_path), hashlib.sha256(head).hexdigest()
+
+    def _read_meta(self, directory: str) -> dict | None:
+        meta_path = self._paths(directory)[2]
+        if not os.path.exists(meta_path):
+            return None
+        with open(meta_path, encoding="utf-8") as f:
+            return json.load(f)
+
+    def has_saved(self, directory: str) -> bool:
+        return os.path.exists(self._paths(directory)[2])
 
     def save(self, directory: str | None = None) -> str:
-        """Persist the collection: the device image (Engine.save), one JSON line per row for the
-        host table (point id + payload, ``null`` for deleted rows) and the folder dictionaries.
-        Returns the directory. Each file is written to ``*.tmp`` and renamed."""
+        """Persist the collection (layout and crash behaviour: comment above). Returns the directory."""
         directory = directory or get_settings().index_dir
         if not directory:
             raise ValueError("no directory given and VOITTA_INDEX_DIR is not set")
         os.makedirs(directory, exist_ok=True)
-        index_path, payload_path, meta_path = self._paths(directory)
         col = self._col
         with col.lock:
-            self.client.save(index_path)
-            with open(payload_path + ".tmp", "w", encoding="utf-8") as f:
+            try:
+                previous = self._read_meta(directory)
+            except (OSError, ValueError):
+                previous = None  # an unreadable pointer names nothing worth keeping
+            generation = int(previous.get("generation", 0)) + 1 if previous else 1
+            index_path, payload_path, meta_path = self._paths(directory, generation)
+            self.client.save(index_path)  # tmp + fsync + rename inside vr_save
+            index_bytes, index_digest = self._index_digest(index_path)
+
+            def write_payload(f):
+                f.write(json.dumps({"format": 2, "generation": generation, "rows": len(col.ids)}) + "\n")
                 for pid, payload in zip(col.ids, col.payload):
                     f.write("null\n" if payload is None else json.dumps({"id": pid, "payload": payload}) + "\n")
-            os.replace(payload_path + ".tmp", payload_path)
-            meta = {"format": 1, "dimension": self.dimension, "rows": len(col.ids),
+
+            self._write_durably(payload_path, write_payload)
+            meta = {"format": 2, "generation": generation, "dimension": self.dimension, "rows": len(col.ids),
+                    "index_file": os.path.basename(index_path), "payload_file": os.path.basename(payload_path),
+                    "index_bytes": index_bytes, "index_header_sha256": index_digest,
                     "folder_ids": col.folder_ids, "index_folder_ids": col.index_folder_ids}
-            with open(meta_path + ".tmp", "w", encoding="utf-8") as f:
-                json.dump(meta, f)
-            os.replace(meta_path + ".tmp", meta_path)
+            self._fsync_dir(directory)
+            self._write_durably(meta_path, lambda f: json.dump(meta, f))  # <- the commit
+            self._fsync_dir(directory)
+            # the generation that was live before, and leftovers of saves that never committed
+            keep = {os.path.basename(index_path), os.path.basename(payload_path), os.path.basename(meta_path)}
+            prefix = self.collection_name + "."
+            for name in os.listdir(directory):
+                rest = name[len(prefix):] if name.startswith(prefix) else ""
+                stale_generation = rest.startswith("g") and rest.split(".", 1)[0][1:].isdigit()
+                legacy = rest in ("vrindex", "payload.jsonl")
+                if name not in keep and (stale_generation or legacy or rest.endswith(".tmp")):
+                    try:
+                        os.remove(os.path.join(directory, name))
+                    except OSError:
+                        pass
         return directory
 
     def load(self, directory: str | None = None) -> int:
@@ -193,28 +268,55 @@ class VectorStoreService:
         return self._load_into(col, directory)
 
     def _load_into(self, col: _Collection, directory: str) -> int:
-        index_path, payload_path, meta_path = self._paths(directory)
-        meta = json.load(open(meta_path, encoding="utf-8"))
-        if meta.get("format") != 1 or meta["dimension"] != self.dimension:
-            raise ValueError(f"{meta_path}: format/dimension mismatch ({meta.get('format')}, {meta.get('dimension')})")
+        """Fills ``col`` and the engine, or raises and leaves both empty (the engine commits a load only after
+        its own checksum held; the host table is built aside and installed last)."""
+        meta_path = self._paths(directory)[2]
+        meta = self._read_meta(directory)
+        if meta is None:
+            raise FileNotFoundError(meta_path)
+        fmt = meta.get("format")
+        if fmt not in (1, 2) or meta.get("dimension") != self.dimension:
+            raise ValueError(f"{meta_path}: format/dimension mismatch ({fmt}, {meta.get('dimension')})")
+        if fmt == 1:
+            index_path, payload_path, _ = self._paths(directory)
+        else:
+            index_path = os.path.join(directory, meta["index_file"])
+            payload_path = os.path.join(directory, meta["payload_file"])
+            for path in (index_path, payload_path):
+                if not os.path.exists(path):
+                    raise ValueError(f"{meta_path} names {os.path.basename(path)}, which is missing")
+            if self._index_digest(index_path) != (meta["index_bytes"], meta["index_header_sha256"]):
+                raise ValueError(f"{index_path} is not the index file generation {meta['generation']} was saved with")
+        ids: list = []
+        payloads: list = []
+        row_of: dict = {}
+        rows_by_file: dict = {}
+        with open(payload_path, encoding="utf-8") as f:
+            if fmt == 2:
+                head = json.loads(f.readline() or "null")
+                if not isinstance(head, dict) or head.get("generation") != meta["generation"] or head.get("rows") != meta["rows"]:
+                    raise ValueError(f"{payload_path} does not belong to generation {meta['generation']}")
+            for line in f:
+                rec = json.loads(line)
+                row = len(ids)
+                if rec is None:
+                    ids.append(None)
+                    payloads.append(None)
+                    continue
+                ids.append(rec["id"])
+                payloads.append(rec["payload"])
+                row_of[rec["id"]] = row
+                rows_by_file.setdefault(rec["payload"]["file_path"], []).append(row)
+        if len(ids) != meta["rows"]:
+            raise ValueError(f"{payload_path}: {len(ids)} rows, the pointer file says {meta['rows']} (truncated?)")
         with col.lock:
             self._client.load(index_path)
-            for line in open(payload_path, encoding="utf-8"):
-                rec = json.loads(line)
-                row = len(col.ids)
-                if rec is None:
-                    col.ids.append(None)
-                    col.payload.append(None)
-                    continue
-                col.ids.append(rec["id"])
-                col.payload.append(rec["payload"])
-                col.row_of[rec["id"]] = row
-                col.rows_by_file.setdefault(rec["payload"]["file_path"], []).append(row)
+            n_rows, _ = self._client.count()
+            if n_rows != len(ids):
+                raise ValueError(f"{directory}: index holds {n_rows} rows, host table {len(ids)}")
+            col.ids, col.payload, col.row_of, col.rows_by_file = ids, payloads, row_of, rows_by_file
             col.folder_ids = {k: int(v) for k, v in meta["folder_ids"].items()}
             col.index_folder_ids = {k: int(v) for k, v in meta["index_folder_ids"].items()}
-            n_rows, _ = self._client.count()
-            if n_rows != len(col.ids) or meta["rows"] != n_rows:
-                raise ValueError(f"{directory}: index holds {n_rows} rows, host table {len(col.ids)}")
         logger.info("Loaded %d rows of collection '%s' from %s", len(col.ids), self.collection_name, directory)
         return len(col.ids)
 
@@ -423,6 +525,8 @@ class VectorStoreService:
                date_start: int | None = None, date_end: int | None = None,
                date_field: str | None = None) -> list[StoredChunk]:
         """Dense or hybrid retrieval with the reference's branch selection (vector_store.py:560-619)."""
+        if limit <= 0:
+            return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
         q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
         with col.lock:
