@@ -259,6 +259,8 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
 #define VR_STAT_TWO_STAGE 0        /* single-query dense searches served by f16 scan + exact re-score */
 #define VR_STAT_FALLBACK 1         /* ... of which exceeded the re-score budget and were redone one-stage */
 #define VR_STAT_LAST_CANDIDATES 2  /* rows re-scored by the last two-stage search */
+#define VR_STAT_BATCHED 3          /* queries served by the batched (integer GEMM) dense search */
+#define VR_STAT_BATCH_FALLBACK 4   /* ... of which exceeded their candidate budget and were redone alone */
 int vr_stats(vr_engine* e, int32_t which, int64_t* out);
 
 /* n_rows = rows ever assigned, n_live = not tombstoned (get_collection_info, vector_store.py:699-710) */
@@ -275,7 +277,10 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 /* ---- search: replaces client.query_points (vector_store.py:612-617, :640-656) ------------- */
 /* q : nq x D f32 (`mem`); results (host): rows[nq*k] (-1 padded), scores[nq*k], counts[nq].
  * Exact f32 brute force over live rows that pass `filter` (NULL = none), score = k-ordered f32
- * fma chain of q_hat . x_hat, ties broken by the lower row id. */
+ * fma chain of q_hat . x_hat, ties broken by the lower row id.
+ * More than 16 queries at once (BASELINE configs[4]: 1k batched queries) are served by an int8
+ * matrix-core GEMM over the shadow corpus with certain error bounds, followed by an exact re-score of
+ * the candidates (csrc/batch.hip): same results, bit for bit, at a small fraction of nq single searches. */
 int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k,
                     const vr_filter* filter,
                     int64_t* rows, float* scores, int32_t* counts);
@@ -297,6 +302,7 @@ float vr_idf(int64_t n_points, int32_t df);
 #define VR_PROF_ATTENTION 1    /* work = FLOP (4 * H * sum len^2) */
 #define VR_PROF_DENSE_SCAN 2   /* work = bytes (N*D*4 + masks + scores) */
 #define VR_PROF_SPARSE_SCAN 3  /* work = bytes (4 per stored id + 5 per row) */
+#define VR_PROF_BATCH_SCAN 4   /* batched dense search, both integer-GEMM passes; work = operations (2*N*D*Q) */
 /* enable != 0 clears earlier records and starts recording one event pair per launch */
 int vr_profile(vr_engine* e, int enable);
 int vr_profile_read(vr_engine* e, int kernel_class, double* total_ms, int64_t* launches,

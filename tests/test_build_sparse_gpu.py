@@ -147,7 +147,7 @@ def test_migrated_collection_against_the_bm25_oracle(native):  # noqa: F811
     n_lost = sum(1 for r in src_rows if r in lost)
     assert (stats["processed"], stats["inserted"], stats["skipped"]) == (n, n, n_lost)
 
-    vs = get_vector_store()
+    emb, vs = get_embedding_service(), get_vector_store()  # (the old services were bound to the closed source engine)
     e = vs.client
     assert e.count() == (n, n)
     # carry-over (:176-194): ids, payloads, dense bits, in the source's order

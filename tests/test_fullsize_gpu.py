@@ -121,3 +121,27 @@ def test_deletes_at_full_size(corpus):
     assert np.array_equal(r2, r1) and np.array_equal(s2, s1)
     assert not set(r[:5].tolist()) & set(r2.tolist()) and np.array_equal(r2[:5], r[5:])
     assert two.count() == (N, N - 5)
+
+
+def test_batched_queries_equal_single_queries_at_full_size(corpus):
+    """configs[4]'s query side on one shard: 1000 queries in ONE call (integer-GEMM batched search) must return, for
+    every query, exactly what 1000 single searches return (two-stage single-query path), and both must agree with the
+    one-stage f32 engine on a sample."""
+    two, one, halves, q, keep = corpus
+    rng = np.random.default_rng(4)
+    qs = rng.standard_normal((1000, D)).astype(np.float32)
+    qs[:24] = q
+    before = two.stats()
+    batched = two.search_dense(qs, 10)
+    after = two.stats()
+    assert after["batched"] - before["batched"] == 1000
+    for i in range(0, 1000, 7):
+        r1, s1 = two.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+    for i in range(0, 24):
+        r1, s1 = one.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+    # 16 queries at a time through the exact f32 scan (the pre-batch path) for a block of them
+    blk = one.search_dense(qs[100:116], 10)
+    for j in range(16):
+        assert np.array_equal(batched[100 + j][0], blk[j][0]) and np.array_equal(batched[100 + j][1], blk[j][1])

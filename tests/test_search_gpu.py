@@ -303,3 +303,68 @@ def test_two_stage_rescoring_by_tile_absorbs_a_tight_cluster(gpu, shadow, monkey
     if shadow == "int8":
         assert st["last_candidates"] > 4096  # the last query sits inside the cluster
     e.close()
+
+
+# ---- batched dense search (csrc/batch.hip; BASELINE configs[4]: 1k batched queries) --------------------------
+
+@pytest.mark.parametrize("dim,n,nq", [(384, 20000, 1000), (1024, 17000, 256), (768, 16500, 17), (128, 30011, 300)])
+def test_batched_dense_search_is_bit_exact(gpu, dim, n, nq):
+    """More than 16 queries in one call go through the int8 matrix-core GEMM + exact re-score; the answer must
+    be the oracle's for every query: ranked rows and f32 score bits, with tombstones and a filter in play."""
+    from voitta_rag_amd.engine import SearchFilter
+
+    rng = np.random.default_rng(dim + nq)
+    x = _corpus(rng, n, dim)
+    x[100:140] = x[100] + 1e-3 * rng.standard_normal((40, dim)).astype(np.float32)  # a tight cluster
+    x[200:205] = x[200]                                                               # exact duplicates: ties
+    folders = rng.integers(0, 5, size=n).astype(np.int32)
+    e = _engine(dim, initial_rows=n)
+    e.upsert(x, folder_ids=folders)
+    dead = rng.choice(n, size=n // 50, replace=False)
+    e.delete_rows(dead)
+    live = np.ones(n, np.uint8)
+    live[dead] = 0
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[0] = x[100]
+    q[1] = x[200] * 3.0
+    q[2] = 0.0  # a zero query: every score 0, ranking by row id
+    xh = ocore.cosine_preprocess(x)
+    want = ocore.dense_scores(ocore.cosine_preprocess(q), xh)
+    before = e.stats()
+    for k, mask, flt in ((10, live, None), (30, live & (folders != 3).astype(np.uint8), SearchFilter(exclude_folders=[3]))):
+        got = e.search_dense(q, k, flt)
+        for i in range(nq):
+            wr, ws = ocore.topk(want[i], k, mask)
+            assert np.array_equal(got[i][0], wr), (dim, n, nq, k, i)
+            assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), (dim, n, nq, k, i)
+    after = e.stats()
+    assert after["batched"] - before["batched"] == 2 * nq  # the batched path served them ...
+    assert after["batch_fallback"] - before["batch_fallback"] <= 6  # ... alone but for the zero / cluster queries
+    # the same queries one at a time (two-stage single-query path): identical
+    for i in (0, 1, 3, nq - 1):
+        r1, s1 = e.search_dense(q[i:i + 1], 10)[0]
+        rb, sb = e.search_dense(q, 10)[i]
+        assert np.array_equal(r1, rb) and np.array_equal(s1.view(np.uint32), sb.view(np.uint32))
+    e.close()
+
+
+def test_batched_search_overflow_falls_back_per_query(gpu):
+    """A corpus of near-duplicates puts more rows inside a query's bound than its candidate budget: that query is
+    redone by the exact scans, the others stay on the batched path, every answer is still the oracle's."""
+    dim, n, nq = 256, 20000, 40
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[:6000] = x[0] + 2e-4 * rng.standard_normal((6000, dim)).astype(np.float32)
+    e = _engine(dim, initial_rows=n)
+    e.upsert(x)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[5] = x[0]
+    q[6] = x[17] + 0.01 * rng.standard_normal(dim).astype(np.float32)
+    want = ocore.dense_scores(ocore.cosine_preprocess(q), ocore.cosine_preprocess(x))
+    got = e.search_dense(q, 10)
+    for i in range(nq):
+        wr, ws = ocore.topk(want[i], 10)
+        assert np.array_equal(got[i][0], wr) and np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), i
+    st = e.stats()
+    assert st["batched"] == nq and 2 <= st["batch_fallback"] <= 10
+    e.close()

@@ -247,6 +247,15 @@ void vr_engine_destroy(vr_engine* e) {
   e->sp_cand.release();
   e->q_ids.release();
   e->q_w.release();
+  e->bq_hat.release();
+  e->bq_params.release();
+  e->bq_best.release();
+  e->bq_thr.release();
+  e->bq_img.release();
+  e->bq_cand.release();
+  e->bq_cnt.release();
+  e->bq_keys.release();
+  e->bq_stage.release();
   if (e->pinned) (void)hipHostFree(e->pinned);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -518,6 +527,8 @@ int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
     case VR_STAT_TWO_STAGE: *out = e->stat_two_stage; break;
     case VR_STAT_FALLBACK: *out = e->stat_fallback; break;
     case VR_STAT_LAST_CANDIDATES: *out = *pin_host<int32_t>(e, kPinCandCount); break;
+    case VR_STAT_BATCHED: *out = e->stat_batched; break;
+    case VR_STAT_BATCH_FALLBACK: *out = e->stat_batch_fallback; break;
     default: set_error("unknown statistic %d", which); return -1;
   }
   return 0;
@@ -583,9 +594,9 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
   const uint64_t* host_keys = pin_host<uint64_t>(e, kPinDenseKeys);
-  for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
-    const int nb = std::min(kQueryBlock, nq - q0);
-    const float* q_dev = stage_query(e, q + static_cast<int64_t>(q0) * e->dim, nb, mem);
+  // one 16-query block through the one-/two-stage scans; results decoded into rows/scores/counts at `at`
+  auto run_block = [&](const float* qsrc, int nb, int qmem, int at) -> int {
+    const float* q_dev = stage_query(e, qsrc, nb, qmem);
     bool two_stage = false;
     VR_TRY(search_dense_block(e, q_dev, nb, k, mask, true, &two_stage));
     VR_HIP(hipStreamSynchronize(e->stream));
@@ -597,11 +608,53 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
       VR_HIP(hipStreamSynchronize(e->stream));
     }
     for (int i = 0; i < nb; ++i) {
-      int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k,
-                              rows + static_cast<int64_t>(q0 + i) * k,
-                              scores + static_cast<int64_t>(q0 + i) * k);
-      if (counts) counts[q0 + i] = static_cast<int32_t>(c);
+      int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k, rows + static_cast<int64_t>(at + i) * k,
+                              scores + static_cast<int64_t>(at + i) * k);
+      if (counts) counts[at + i] = static_cast<int32_t>(c);
     }
+    return 0;
+  };
+  if (batch_usable(e, nq, k)) {
+    // many queries at once: integer GEMM over the int8 shadow + exact re-score (batch.hip), 1024 queries per round
+    constexpr int kRound = 1024;
+    std::vector<uint64_t> keys(static_cast<size_t>(std::min(nq, kRound)) * k);
+    std::vector<int32_t> over(static_cast<size_t>(std::min(nq, kRound)));
+    for (int q0 = 0; q0 < nq; q0 += kRound) {
+      const int nb = std::min(kRound, nq - q0);
+      const float* q_dev = q + static_cast<int64_t>(q0) * e->dim;
+      if (mem == VR_MEM_HOST) {
+        VR_TRY(e->bq_stage.grow(static_cast<int64_t>(nb) * e->dim, 0, e->stream));
+        VR_HIP(hipMemcpyAsync(e->bq_stage.p, q_dev, sizeof(float) * static_cast<size_t>(nb) * e->dim, hipMemcpyHostToDevice,
+                              e->stream));
+        q_dev = e->bq_stage.p;
+      }
+      const uint64_t* keys_dev = nullptr;
+      const int32_t* over_dev = nullptr;
+      VR_TRY(batch_search(e, q_dev, nb, k, mask, &keys_dev, &over_dev));
+      VR_HIP(hipMemcpyAsync(keys.data(), keys_dev, sizeof(uint64_t) * static_cast<size_t>(nb) * k, hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipMemcpyAsync(over.data(), over_dev, sizeof(int32_t) * static_cast<size_t>(nb), hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));
+      e->stat_batched += nb;
+      for (int i = 0; i < nb; ++i) {
+        if (over[static_cast<size_t>(i)]) {  // candidate budget exceeded: this query alone, through the exact scans
+          ++e->stat_batch_fallback;
+          if (mem == VR_MEM_HOST) {
+            VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, VR_MEM_HOST, q0 + i));
+          } else {
+            VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, VR_MEM_DEVICE, q0 + i));
+          }
+          continue;
+        }
+        int64_t c = decode_keys(keys.data() + static_cast<int64_t>(i) * k, k, rows + static_cast<int64_t>(q0 + i) * k,
+                                scores + static_cast<int64_t>(q0 + i) * k);
+        if (counts) counts[q0 + i] = static_cast<int32_t>(c);
+      }
+    }
+    return 0;
+  }
+  for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
+    const int nb = std::min(kQueryBlock, nq - q0);
+    VR_TRY(run_block(q + static_cast<int64_t>(q0) * e->dim, nb, mem, q0));
   }
   return 0;
 }

@@ -1,0 +1,435 @@
+// Batched dense search: hundreds to thousands of queries against the whole corpus in one pass —
+// BASELINE configs[4] ("1k batched queries, QPS + recall@10"), the batched form of
+// client.query_points(query=vec, limit=k) (reference: src/voitta/services/vector_store.py:612-617,640-645;
+// the caller that would batch is the MCP search tool, mcp_server.py:469-485, under load).
+//
+// The answer is, bit for bit, what the one-stage f32 scan (dense.hip) returns for every query; the
+// work is organised as the two-stage search of prefilter.hip, with stage 1 turned into a real
+// integer GEMM on the matrix cores:
+//   prep     every query is cosine-preprocessed exactly as dense.hip does it (sequential f32 sum of
+//            squares, the same keep rule and divisions), kept as q^ (f32) and quantised into TWO int8
+//            vectors, q^ = a qa + b qb + rho (b = a / 254), tiled for v_mfma_i32_16x16x64_i8 like the
+//            int8 shadow of the corpus, with its constants (a, b, |q^|, |rho|, fixed error term).
+//   scan     [N rows x D] int8 shadow  x  [D x 2Q] int8 query parts: 256 rows x 128 queries per block
+//            (8 waves as 2 x 4, 128 rows x 32 queries x {a, b} per wave = 128 accumulator registers),
+//            128-deep K-tiles staged through two 64-KiB LDS buffers by direct-to-LDS loads (the shadow
+//            and the query images are already MFMA-operand shaped 1-KiB blocks: linear LDS images,
+//            conflict-free 16-byte fragment reads). The epilogue turns the two exact int32 dot products
+//            into the approximate score A = s_r (a dot_a + b dot_b) and the CERTAIN bound E of
+//            prefilter_scan8_kernel (residual norms by Cauchy-Schwarz; same formula, same constants).
+//            It runs twice:
+//              pass 1  per (128-row slab, query): the best LOWER bound A - E  ->  T_q = k-th largest of
+//                      them. Each is the lower bound of a different row, so at least k rows score >= T_q.
+//              pass 2  rows with A + E >= T_q are the candidates of query q (a superset of its top k).
+//            Two passes of integer MFMAs are cheaper than storing N x Q bounds (4 GB per 1k queries at 1M rows).
+//   rescore  every (query, candidate row) pair is scored with the exact k-ordered f32 fma chain (one lane per
+//            pair; the MFMA chain of dense.hip is bit for bit this chain) and ranked by the usual 64-bit keys.
+// A query whose candidates overflow its budget (a corpus of near-duplicates) is flagged; the host redoes
+// those with the one-stage 16-query scan, so the result never depends on the bound being tight.
+//
+// Roofline: int8 MFMA. Algorithmic work = 2 N D Q operations per pass that matters (SURVEY.md §8d counts the
+// dense top-k of Q batched queries as 2 N D Q); executed: 2 passes x 2 query parts = 4x that on the int8 pipe.
+
+#include "engine_internal.h"
+#include "topk_device.h"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace vr {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+constexpr int kBQ = 128;          // queries per block column
+constexpr int kBR = 256;          // corpus rows per block
+constexpr int kBStage = 64 * 1024;  // bytes per stage: 16 tiles x 2 kb8 KiB of rows + 8 qfrags x {a,b} x 2 kb8 KiB
+constexpr int kBatchCand = 1024;  // candidate budget per query
+constexpr int kQParams = 8;       // floats per query: a, b, |q|, |rho|, c_fixed, (3 spare)
+
+// ---- prep ---------------------------------------------------------------------------------------------
+
+// one block per query. Writes q^ (natural order), the two int8 images and the constants.
+__global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict__ q, int nq, int dim, int kb8n,
+                                                         float* __restrict__ qhat, int8_t* __restrict__ img_a,
+                                                         int8_t* __restrict__ img_b, float* __restrict__ params) {
+  extern __shared__ __align__(16) float row[];  // [dim]
+  __shared__ float red[3][4];
+  __shared__ float len_s;
+  const int qi = blockIdx.x;
+  for (int i = threadIdx.x; i < dim; i += 256) row[i] = q[static_cast<int64_t>(qi) * dim + i];
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the sequential chain of row_length_kernel / query_image_kernel (dense.hip)
+    const float4* p = reinterpret_cast<const float4*>(row);
+    float acc = 0.0f;
+    for (int k = 0; k < dim / 4; ++k) {
+      const float4 v = p[k];
+      acc = __fadd_rn(acc, __fmul_rn(v.x, v.x));
+      acc = __fadd_rn(acc, __fmul_rn(v.y, v.y));
+      acc = __fadd_rn(acc, __fmul_rn(v.z, v.z));
+      acc = __fadd_rn(acc, __fmul_rn(v.w, v.w));
+    }
+    const bool keep = (acc < FLT_EPSILON) || (fabsf(__fadd_rn(acc, -1.0f)) <= 1.0e-6f);
+    len_s = keep ? 0.0f : __fsqrt_rn(acc);
+  }
+  __syncthreads();
+  const float len = len_s;
+  float mx = 0.0f, n2 = 0.0f;
+  for (int i = threadIdx.x; i < dim; i += 256) {
+    float v = row[i];
+    if (len > 0.0f) v = __fdiv_rn(v, len);
+    row[i] = v;
+    qhat[static_cast<int64_t>(qi) * dim + i] = v;
+    mx = fmaxf(mx, fabsf(v));
+    n2 += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+    n2 += __shfl_xor(n2, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mx;
+    red[1][threadIdx.x >> 6] = n2;
+  }
+  __syncthreads();
+  const float t = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  const float qn2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  // the quantisation of prefilter_scan8_kernel, term for term
+  const bool q_ok = t > 0.0f && t <= 3.0e38f;
+  const float a = q_ok ? t / 127.0f : 0.0f;
+  const float inv_a = q_ok ? 127.0f / t : 0.0f;
+  const float b = a / 254.0f;
+  const float inv_b = a > 0.0f ? 254.0f / a : 0.0f;
+  float rho2 = 0.0f;
+  const int frag = qi >> 4, col = qi & 15;
+  for (int kk = threadIdx.x; kk < dim; kk += 256) {
+    const float v = row[kk];
+    const float ta = fminf(fmaxf(rintf(v * inv_a), -127.0f), 127.0f);
+    const float r = v - a * ta;
+    const float tb = fminf(fmaxf(rintf(r * inv_b), -127.0f), 127.0f);
+    const float rho = r - b * tb;
+    rho2 += rho * rho;
+    // [qfrag][kb8][lane = (k % 64) / 16 * 16 + query % 16][16 bytes]
+    const int64_t at = ((static_cast<int64_t>(frag) * kb8n + kk / 64) * 64 + ((kk % 64) / 16) * 16 + col) * 16 + kk % 16;
+    img_a[at] = static_cast<int8_t>(ta);
+    img_b[at] = static_cast<int8_t>(tb);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) rho2 += __shfl_xor(rho2, off);
+  if ((threadIdx.x & 63) == 0) red[2][threadIdx.x >> 6] = rho2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float rho2_all = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float qn = sqrtf(qn2) * 1.0001f + 1.0e-12f;
+    const float rho_n = q_ok ? sqrtf(rho2_all) * 1.001f + 3.0e-7f * qn + 1.0e-12f : __builtin_inff();
+    const float c_fixed = static_cast<float>(dim) * 5.0e-7f * fmaxf(qn, 1.0f) + 1.0e-7f * qn * sqrtf(static_cast<float>(dim));
+    float* p = params + static_cast<int64_t>(qi) * kQParams;
+    p[0] = a;
+    p[1] = b;
+    p[2] = qn;
+    p[3] = rho_n;
+    p[4] = c_fixed;
+  }
+}
+
+// ---- scan ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void glds16b(const void* src, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// grid: x = row block (256 rows) interleaved with query chunk so that the chunks of one row block run on one
+// XCD back to back (they share the rows through its L2), see the index arithmetic below.
+// PASS 1: best[q][128-row slab] = max lower bound (slab = row block x wave row). PASS 2: rows with upper bound >= thr[q] -> cand[q][...].
+template <int PASS>
+__global__ __launch_bounds__(512) void batch_scan_kernel(
+    const uint4* __restrict__ corpus8, const uint4* __restrict__ img_a, const uint4* __restrict__ img_b,
+    const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
+    const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int n_qc, int nq, int kb8n,
+    float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt) {
+  __shared__ uint4 lds[2 * kBStage / 16];  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
+  // blocks b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart
+  const int bid = blockIdx.x;
+  const int lane8 = bid & 7, rest = bid >> 3;
+  const int qc = rest % n_qc;
+  const int rb = (rest / n_qc) * 8 + lane8;
+  if (rb >= n_rb) return;  // block-uniform
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = kb8n / 2;  // 128-deep K-tiles (kb8n is even: dim % 128 == 0)
+
+  // staging: wave w moves the 1-KiB blocks (row tile w, w + 8) x (kb8 0, 1) of the shadow and the blocks
+  // (qfrag w) x {a, b} x (kb8 0, 1) of the query images; every block is one wave-wide 16-byte-per-lane load
+  const int64_t tile0 = static_cast<int64_t>(rb) * 16;
+  const int64_t last_tile = n_tiles - 1;
+  const uint4* gA0 = corpus8 + std::min<int64_t>(tile0 + wave, last_tile) * kb8n * 64 + lane;
+  const uint4* gA1 = corpus8 + std::min<int64_t>(tile0 + wave + 8, last_tile) * kb8n * 64 + lane;
+  const int64_t qf = static_cast<int64_t>(qc) * 8 + wave;  // (images are padded to whole chunks of 128 queries)
+  const uint4* gBa = img_a + qf * kb8n * 64 + lane;
+  const uint4* gBb = img_b + qf * kb8n * 64 + lane;
+  // LDS image of a stage, in 1-KiB blocks: rows  [tile 0..15][kb 0..1] = block 2 t + c;
+  //                                        query [qfrag 0..7][part a, b][kb 0..1] = block 32 + 4 f + 2 p + c
+  auto stage = [&](int buf, int kt) {
+    uint4* d = lds + buf * (kBStage / 16);
+    const int k0 = 2 * kt * 64;
+    glds16b(gA0 + k0, d + (2 * wave) * 64);
+    glds16b(gA0 + k0 + 64, d + (2 * wave + 1) * 64);
+    glds16b(gA1 + k0, d + (2 * (wave + 8)) * 64);
+    glds16b(gA1 + k0 + 64, d + (2 * (wave + 8) + 1) * 64);
+    glds16b(gBa + k0, d + (32 + 4 * wave) * 64);
+    glds16b(gBa + k0 + 64, d + (32 + 4 * wave + 1) * 64);
+    glds16b(gBb + k0, d + (32 + 4 * wave + 2) * 64);
+    glds16b(gBb + k0 + 64, d + (32 + 4 * wave + 3) * 64);
+  };
+
+  i32x4 acc[8][2][2];  // [row tile of the wave][qfrag of the wave][part a, b]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) acc[i][f][0] = acc[i][f][1] = i32x4{0, 0, 0, 0};
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint4* st = lds + (kt & 1) * (kBStage / 16);
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 bf[2][2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[f][p] = st[(32 + 4 * (2 * wn + f) + 2 * p + c) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 af = st[(2 * (8 * wm + i) + c) * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            acc[i][f][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(&af),
+                                                                 *reinterpret_cast<const i32x4*>(&bf[f][p]),
+                                                                 acc[i][f][p], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile
+  const int g = lane >> 4;
+  float pa[2], pb[2], pqn[2], prho[2], pcf[2], pthr[2], run[2];
+  int qidx[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
+    const float* p = params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams;
+    pa[f] = p[0];
+    pb[f] = p[1];
+    pqn[f] = p[2];
+    prho[f] = p[3];
+    pcf[f] = p[4];
+    pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
+    run[f] = -__builtin_inff();
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t tile = tile0 + 8 * wm + i;
+    if (tile > last_tile) break;  // wave-uniform
+    const int64_t row0 = tile * kTileRows + 4 * g;
+    const uchar4 m = *reinterpret_cast<const uchar4*>(mask + row0);
+    const float4 e4 = *reinterpret_cast<const float4*>(row_err + row0);
+    const float4 s4 = *reinterpret_cast<const float4*>(row_scale + row0);
+    const unsigned char mm[4] = {m.x, m.y, m.z, m.w};
+    const float ee[4] = {e4.x, e4.y, e4.z, e4.w};
+    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // exactly prefilter_scan8_kernel's arithmetic
+        const float fa = pa[f] * static_cast<float>(acc[i][f][0][r]);
+        const float fb = pb[f] * static_cast<float>(acc[i][f][1][r]);
+        const float score = ss[r] * (fa + fb);
+        const float err = ee[r] * pqn[f] + (1.001f + ee[r]) * prho[f] + pcf[f] + 2.0e-6f * ss[r] * (fabsf(fa) + fabsf(fb));
+        if (PASS == 1) {
+          if (mm[r]) run[f] = fmaxf(run[f], score - err);
+        } else if (mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
+          const int slot = atomicAdd(cand_cnt + qidx[f], 1);
+          if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
+        }
+      }
+  }
+  if (PASS == 1) {
+    // this wave's 128 rows -> one value per query (the four lane groups hold different rows of the same queries)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float v = run[f];
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rb + wm] = v;
+    }
+  }
+}
+
+// thr[q] = score of the k-th best key of query q (keys: [nq][k], descending, zero padded); fewer than k rows
+// in play: every row with a finite bound is a candidate
+__global__ void batch_threshold_kernel(const uint64_t* __restrict__ keys, int nq, int k, float* __restrict__ thr) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const uint64_t kth = keys[static_cast<int64_t>(q) * k + (k - 1)];
+  float t = -3.0e38f;
+  if (kth) {
+    const uint32_t hi = static_cast<uint32_t>(kth >> 32);
+    t = __uint_as_float((hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi);
+  }
+  thr[q] = t;
+}
+
+// ---- exact re-score of the (query, candidate row) pairs --------------------------------------------------
+
+// One lane per pair: the k-ordered f32 fma chain from +0.0 over the stored (tiled) row and q^ — bit for bit what
+// the v_mfma_f32_16x16x4_f32 chain of dense.hip returns. keys[q][slot] (0 beyond the query's count).
+__global__ __launch_bounds__(256) void batch_rescore_kernel(const float4* __restrict__ corpus,
+                                                            const float* __restrict__ qhat,
+                                                            const int32_t* __restrict__ cand,
+                                                            const int32_t* __restrict__ cand_cnt, int nq, int dim,
+                                                            int kblocks, uint64_t* __restrict__ keys) {
+  const int64_t pair = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int q = static_cast<int>(pair / kBatchCand), slot = static_cast<int>(pair % kBatchCand);
+  if (q >= nq) return;
+  uint64_t key = 0ull;
+  if (slot < min(cand_cnt[q], kBatchCand)) {
+    const int64_t row = cand[pair];
+    const int64_t tile = row / kTileRows;
+    const int r = static_cast<int>(row % kTileRows);
+    const float4* x = corpus + tile * kblocks * 64 + r;  // block kb: float4 at lane g * 16 + r holds k = 16 kb + 4 c + g
+    const float4* qv = reinterpret_cast<const float4*>(qhat + static_cast<int64_t>(q) * dim);
+    float acc = 0.0f;
+    for (int kb = 0; kb < kblocks; ++kb) {
+      const float4 x0 = x[kb * 64], x1 = x[kb * 64 + 16], x2 = x[kb * 64 + 32], x3 = x[kb * 64 + 48];  // g = 0..3
+      const float4 q0 = qv[kb * 4], q1 = qv[kb * 4 + 1], q2 = qv[kb * 4 + 2], q3 = qv[kb * 4 + 3];       // c = 0..3
+      acc = fmaf(x0.x, q0.x, acc);  // k = 16 kb + 0 .. 3: c = 0, g = 0..3
+      acc = fmaf(x1.x, q0.y, acc);
+      acc = fmaf(x2.x, q0.z, acc);
+      acc = fmaf(x3.x, q0.w, acc);
+      acc = fmaf(x0.y, q1.x, acc);  // c = 1
+      acc = fmaf(x1.y, q1.y, acc);
+      acc = fmaf(x2.y, q1.z, acc);
+      acc = fmaf(x3.y, q1.w, acc);
+      acc = fmaf(x0.z, q2.x, acc);  // c = 2
+      acc = fmaf(x1.z, q2.y, acc);
+      acc = fmaf(x2.z, q2.z, acc);
+      acc = fmaf(x3.z, q2.w, acc);
+      acc = fmaf(x0.w, q3.x, acc);  // c = 3
+      acc = fmaf(x1.w, q3.y, acc);
+      acc = fmaf(x2.w, q3.z, acc);
+      acc = fmaf(x3.w, q3.w, acc);
+    }
+    key = topk_make_key(acc, row);
+  }
+  keys[pair] = key;
+}
+
+// one block per query: the k best of its <= kBatchCand exact keys (k rounds of block-wide extract-max),
+// and the overflow flag for the host
+__global__ __launch_bounds__(256) void batch_final_kernel(const uint64_t* __restrict__ keys,
+                                                          const int32_t* __restrict__ cand_cnt, int k,
+                                                          uint64_t* __restrict__ out, int32_t* __restrict__ overflow) {
+  __shared__ uint64_t wmax[2][4];
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t v[kBatchCand / 256];
+  uint64_t lmax = 0;
+#pragma unroll
+  for (int i = 0; i < kBatchCand / 256; ++i) {
+    v[i] = keys[static_cast<int64_t>(q) * kBatchCand + i * 256 + threadIdx.x];
+    lmax = v[i] > lmax ? v[i] : lmax;
+  }
+  if (threadIdx.x == 0) overflow[q] = cand_cnt[q] > kBatchCand;
+  for (int r = 0; r < k; ++r) {
+    uint64_t m = lmax;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint64_t o = __shfl_xor(m, off);
+      m = o > m ? o : m;
+    }
+    if (lane == 0) wmax[r & 1][wave] = m;
+    __syncthreads();
+    uint64_t bestk = wmax[r & 1][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) bestk = wmax[r & 1][w] > bestk ? wmax[r & 1][w] : bestk;
+    if (threadIdx.x == 0) out[static_cast<int64_t>(q) * k + r] = bestk;
+    if (bestk != 0 && lmax == bestk) {  // keys are unique: exactly one owner
+      lmax = 0;
+#pragma unroll
+      for (int i = 0; i < kBatchCand / 256; ++i) {
+        if (v[i] == bestk) v[i] = 0;
+        lmax = v[i] > lmax ? v[i] : lmax;
+      }
+    }
+  }
+}
+
+bool batch_usable(vr_engine* e, int nq, int k) {
+  static const bool off = getenv("VR_BATCH_SEARCH") && atoi(getenv("VR_BATCH_SEARCH")) == 0;
+  return !off && e->prefilter8 && e->dim % 128 == 0 && nq > kQueryBlock && k <= kFusedMaxK && e->n_rows >= 16384;
+}
+
+// q_dev: nq x D raw queries on the device. Leaves nq x k keys in out_keys_dev and one overflow flag per query
+// in overflow_dev (device memory owned by the engine; the caller copies both back).
+int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t* mask_dev, const uint64_t** out_keys_dev,
+                 const int32_t** overflow_dev) {
+  hipStream_t s = e->stream;
+  const int dim = e->dim, kb8n = dim / 64;
+  const int64_t n_tiles = (e->n_rows + kTileRows - 1) / kTileRows;
+  const int n_rb = static_cast<int>((n_tiles + 15) / 16);
+  const int n_qc = (nq + kBQ - 1) / kBQ;
+  const int64_t nq_pad = static_cast<int64_t>(n_qc) * kBQ;
+  VR_TRY(e->bq_hat.grow(static_cast<int64_t>(nq) * dim, 0, s));
+  VR_TRY(e->bq_img.grow(2 * nq_pad * dim / 4, 0, s));  // two int8 images, counted in int32
+  VR_TRY(e->bq_params.grow(static_cast<int64_t>(nq) * kQParams, 0, s));
+  VR_TRY(e->bq_best.grow(static_cast<int64_t>(nq) * 2 * n_rb, 0, s));
+  VR_TRY(e->bq_thr.grow(nq, 0, s));
+  VR_TRY(e->bq_cand.grow(static_cast<int64_t>(nq) * kBatchCand, 0, s));
+  VR_TRY(e->bq_cnt.grow(2 * static_cast<int64_t>(nq), 0, s));  // counts, then overflow flags
+  VR_TRY(e->bq_keys.grow(static_cast<int64_t>(nq) * kBatchCand + static_cast<int64_t>(nq) * k, 0, s));
+  int8_t* img_a = reinterpret_cast<int8_t*>(e->bq_img.p);
+  int8_t* img_b = img_a + nq_pad * dim;
+  VR_HIP(hipMemsetAsync(e->bq_img.p, 0, static_cast<size_t>(2 * nq_pad * dim), s));  // padding queries: zeros
+  VR_HIP(hipMemsetAsync(e->bq_cnt.p, 0, sizeof(int32_t) * 2 * static_cast<size_t>(nq), s));
+  hipLaunchKernelGGL(batch_prep_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), static_cast<size_t>(dim) * sizeof(float),
+                     s, q_dev, nq, dim, kb8n, e->bq_hat.p, img_a, img_b, e->bq_params.p);
+  const unsigned grid = static_cast<unsigned>(((n_rb + 7) / 8) * n_qc * 8);
+  // algorithmic work of the batched scan: 2 N D Q operations (the second pass and the second query part are overhead)
+  prof_begin(e, VR_PROF_BATCH_SCAN, 2.0 * static_cast<double>(e->n_rows) * dim * nq);
+  hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+                     reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
+                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, n_qc, nq, kb8n, e->bq_best.p,
+                     static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
+  const uint64_t* kth = nullptr;
+  VR_TRY(topk_select(e, e->bq_best.p, 2 * n_rb, 2 * n_rb, nq, k, &kth));
+  hipLaunchKernelGGL(batch_threshold_kernel, dim3(static_cast<unsigned>((nq + 255) / 256)), dim3(256), 0, s, kth, nq, k,
+                     e->bq_thr.p);
+  hipLaunchKernelGGL((batch_scan_kernel<2>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+                     reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
+                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, n_qc, nq, kb8n, static_cast<float*>(nullptr),
+                     e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p);
+  prof_end(e);
+  uint64_t* keys = e->bq_keys.p;
+  uint64_t* out = keys + static_cast<int64_t>(nq) * kBatchCand;
+  hipLaunchKernelGGL(batch_rescore_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(nq) * kBatchCand / 256)), dim3(256),
+                     0, s, reinterpret_cast<const float4*>(e->corpus.p), e->bq_hat.p, e->bq_cand.p, e->bq_cnt.p, nq, dim,
+                     e->kblocks, keys);
+  hipLaunchKernelGGL(batch_final_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, s, keys, e->bq_cnt.p, k, out,
+                     e->bq_cnt.p + nq);
+  VR_HIP(hipGetLastError());
+  *out_keys_dev = out;
+  *overflow_dev = e->bq_cnt.p + nq;
+  return 0;
+}
+
+}  // namespace vr

@@ -416,6 +416,24 @@ __global__ __launch_bounds__(256) void gather_first_rows_ln_kernel(const float* 
     dst[static_cast<int64_t>(i) * H + c] = ln_apply(pre[static_cast<int64_t>(t) * H + c], st.x, st.y, g[c], b[c]);
 }
 
+// the same from f16 pre-LN rows (f16 residual stream, see EPI_RLS_*)
+__global__ __launch_bounds__(256) void gather_first_rows_ln16_kernel(const half_t* __restrict__ pre,
+                                                                     const float2* __restrict__ stat,
+                                                                     const float* __restrict__ g,
+                                                                     const float* __restrict__ b,
+                                                                     const int32_t* __restrict__ cu, int seq0,
+                                                                     int tok_base, int n, int T, int H,
+                                                                     float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int t = min(cu[seq0 + i] - tok_base, T - 1);
+  const float2 st = stat[t];
+  for (int c = lane; c < H; c += 64)
+    dst[static_cast<int64_t>(i) * H + c] =
+        ln_apply(static_cast<float>(pre[static_cast<int64_t>(t) * H + c]), st.x, st.y, g[c], b[c]);
+}
+
 // ---- GEMM: C[M,N] = A[M,K] W[N,K]^T + bias (+ GELU | + R) ---------------------------------------
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -429,7 +447,14 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_F16 = 3,
        //   epilogue applies the row statistics (FOLD_*: bias = c, ln_g = colsum, ln_stat = (mean, 1/sigma));
        //   the producer (RESIDUAL_LN_STATS) also stores its output rows as f16 and per-(row, 64 columns)
        //   partial (sum, sum of squares), from which ln_finalize_kernel makes the statistics.
-       EPI_FOLD_F16 = 5, EPI_FOLD_GELU = 6, EPI_BIAS_RESIDUAL_LN_STATS = 7 };
+       EPI_FOLD_F16 = 5, EPI_FOLD_GELU = 6, EPI_BIAS_RESIDUAL_LN_STATS = 7,
+       // ... with an f16 RESIDUAL STREAM (gemm_f16_pp_kernel only): the pre-LayerNorm rows exist as f16 only — the
+       // array the next projection reads anyway — so the producer stores 2 bytes per element instead of 6 and
+       // the residual read is 2 bytes instead of 4 (the statistics still come from the f32 sums before the
+       // rounding). R32_O16: residual rows still f32 (layer 0: the embedding sum), f16 out; R16_O16: f16 in and
+       // out, IN PLACE (every element is read and written by the same lane); R16_O32: f16 in, f32 + f16 out
+       // (the last layer of a mean-pooled model: the final LayerNorm and the pooling read f32 rows).
+       EPI_RLS_R32_O16 = 8, EPI_RLS_R16_O16 = 9, EPI_RLS_R16_O32 = 10 };
 
 // Linear tile id -> (row panel, column panel), row panels taken kGroupM at a time with the column
 // index slow inside a group. The ~32 blocks an XCD runs together then cover ~8 row panels x ~4
@@ -1117,7 +1142,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Wh, const float* __restrict__ bias,
     const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
     int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
-    const float* __restrict__ ln_b) {
+    const float* __restrict__ ln_b, int stagger_sleeps) {
   __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
   const int tiles_n = (N + GBN - 1) / GBN;
   const int tiles_m = (M + GBM - 1) / GBM;
@@ -1141,6 +1166,13 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  // Phase diversity: every block's tile takes the same time, so without this all 256 CUs reach their
+  // epilogues together — a burst of stores at the chip's store bandwidth with every matrix pipe idle,
+  // followed by a main loop with the store path idle. Block `local` (of G) starts local / G of
+  // `stagger_sleeps` x 64 cycles late, which spreads the epilogues over the tile period. The blocks with
+  // the highest index — the ones that sleep longest — are also the ones that get one tile FEWER when the
+  // tile count is not a multiple of G, so most of the delay falls into the last, partly filled round.
+  for (int d = (static_cast<int64_t>(stagger_sleeps) * local) / G; d > 0; d -= 16) __builtin_amdgcn_s_sleep(16);
 
   // staging: one direct-to-LDS load moves 8 rows x 128 B; lane -> row (lane >> 3) of the 8, LDS chunk
   // (lane & 7), source chunk (lane & 7) ^ ((row >> 1) & 7). Wave w stages A rows 8w + {0, 128} (the rows
@@ -1347,11 +1379,14 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const int tok = lane & 15, fg = lane >> 4;
     const int fbase = bn + wn * 64 + 8 * fg;  // + 32 p (+ 4 q): this lane's features
     constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
-    constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS;
+    constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS || EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16 ||
+                            EPI == EPI_RLS_R16_O32;
+    constexpr bool kR16 = EPI == EPI_RLS_R16_O16 || EPI == EPI_RLS_R16_O32;   // residual rows are f16
+    constexpr bool kNoOut32 = EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16;  // pre-LN rows go out as f16 only
     constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
     constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
     constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
-    constexpr bool kHalfOut = kGelu || EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16;
+    constexpr bool kHalfOut = kGelu || EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16 || kNoOut32;
     float s1[8], s2[8];  // kStats: this lane's share of the row sums, per piece
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) s1[pc] = s2[pc] = 0.0f;
@@ -1375,7 +1410,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       float2 st2[2] = {};
       auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
         const int64_t rr = min(bm + wm * 128 + 16 * pc + tok, M - 1);
-        if (kResidual) {
+        if (kResidual && kR16) {  // eight f16 residual values: carried in r[0]'s 16 bytes
+          r[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const half_t*>(R) + rr * N + cs);
+        } else if (kResidual) {
           r[0] = *reinterpret_cast<const float4*>(R + rr * N + cs);
           r[1] = *reinterpret_cast<const float4*>(R + rr * N + cs + 4);
         }
@@ -1394,8 +1431,13 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
           const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
           const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
           const float lb[4] = {lb4[q].x, lb4[q].y, lb4[q].z, lb4[q].w};
-          const float4 rq = r4[pc & 1][q];
-          const float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
+          const float4 rq = r4[pc & 1][kR16 ? 0 : q];
+          float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
+          if (kR16) {
+            const f16x8 rh = *reinterpret_cast<const f16x8*>(&rq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr4[r] = static_cast<float>(rh[4 * q + r]);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = acc[pc][2 * p2 + q][r];
@@ -1707,9 +1749,21 @@ static void launch_256(int epi, int grid, hipStream_t s, const half_t* Ah, const
 #undef VR_LAUNCH_256
 }
 
+// the ping-pong kernel serves the f16 mode when K is whole pairs of 64-deep K-tiles and a lane's 8 features are in
+// or out of N together; VR_GEMM_PP=0 keeps the one-barrier-per-K-tile loop (A/B runs)
+static bool pp_usable(int N, int K) {
+  static const bool pp_on = !(getenv("VR_GEMM_PP") && atoi(getenv("VR_GEMM_PP")) == 0);
+  return pp_on && K % 128 == 0 && N % 8 == 0;
+}
+
 static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Wh, const float* bias,
                       const float* R, float* C, half_t* Ch, half_t* Cl, int M, int N, int K, float unscale,
                       const float2* ln_stat, const float* ln_g, const float* ln_b) {
+  // start-time spread of the persistent blocks, as a fraction of one tile's time (estimated: ~2400 cycles per
+  // K-tile + ~12000 of epilogue, in units of 64 cycles); only when a block walks several tiles
+  static const float stagger_frac = getenv("VR_GEMM_STAGGER") ? static_cast<float>(atof(getenv("VR_GEMM_STAGGER"))) : 0.0f;
+  const int tiles_total = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+  const int stagger = tiles_total >= 3 * grid ? static_cast<int>(stagger_frac * ((K / 64) * 2400.0f + 12000.0f) / 64.0f) : 0;
 #ifdef VR_GEMM_DIAG_BUILD
   static bool diag_set = false;
   if (!diag_set) {
@@ -1720,7 +1774,7 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
 #endif
 #define VR_LAUNCH_PP(E)                                                                                        \
   hipLaunchKernelGGL((gemm_f16_pp_kernel<E>), dim3(grid), dim3(512), 0, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, \
-                     unscale, ln_stat, ln_g, ln_b)
+                     unscale, ln_stat, ln_g, ln_b, stagger)
   switch (epi) {
     case EPI_BIAS: VR_LAUNCH_PP(EPI_BIAS); break;
     case EPI_BIAS_GELU: VR_LAUNCH_PP(EPI_BIAS_GELU); break;
@@ -1729,6 +1783,9 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
     case EPI_FOLD_F16: VR_LAUNCH_PP(EPI_FOLD_F16); break;
     case EPI_FOLD_GELU: VR_LAUNCH_PP(EPI_FOLD_GELU); break;
     case EPI_BIAS_RESIDUAL_LN_STATS: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL_LN_STATS); break;
+    case EPI_RLS_R32_O16: VR_LAUNCH_PP(EPI_RLS_R32_O16); break;
+    case EPI_RLS_R16_O16: VR_LAUNCH_PP(EPI_RLS_R16_O16); break;
+    case EPI_RLS_R16_O32: VR_LAUNCH_PP(EPI_RLS_R16_O32); break;
     default: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL); break;
   }
 #undef VR_LAUNCH_PP
@@ -1937,9 +1994,7 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
     }
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     const int grid256 = std::min(tiles, n_cu);
-    // f16 mode: the ping-pong main loop (gemm_f16_pp_kernel); VR_GEMM_PP=0 keeps the one-barrier-per-K-tile loop
-    static const bool pp_on = !(getenv("VR_GEMM_PP") && atoi(getenv("VR_GEMM_PP")) == 0);
-    if (passes == 1 && pp_on && K % 128 == 0 && N % 8 == 0)
+    if (passes == 1 && pp_usable(N, K))  // f16 mode: the ping-pong main loop (gemm_f16_pp_kernel)
       launch_pp(epi, grid256, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
     else if (passes == 1)
       launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
@@ -2497,6 +2552,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   float2* stat_a = reinterpret_cast<float2*>(enc->lnstat);
   float2* stat_b = plain ? stat_a + T : nullptr;
   Hidden cur{enc->x, stat_b, enc->lng, enc->lnb};
+  bool cur16 = false;  // f16 residual stream: the current pre-LN rows are the f16 rows in xh (cur.pre is stale)
   const float* final_x = enc->x;  // the f32 rows pooling reads
   const bool lnfuse = plain && !enc->layers.empty();  // (a model without layers pools the embedding LayerNorm's output)
   // a handful of tokens (one query): the two LayerNorm launches of a layer are folded into the projections
@@ -2509,6 +2565,9 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   // gain-scaled weights and applies the statistics in its epilogue (EPI_FOLD_*). VR_ENCODE_FOLD_GEMM=0: off.
   static const bool fold_big_enabled = !(getenv("VR_ENCODE_FOLD_GEMM") && atoi(getenv("VR_ENCODE_FOLD_GEMM")) == 0);
   const bool fold_big = lnfuse && fold_big_enabled && T > 4 * kSkinnyM && H % 64 == 0 && enc->layers[0].cs_1 != nullptr;
+  // ... and with an f16 residual stream (EPI_RLS_*): the pre-LayerNorm rows live in xh only. VR_ENCODE_RES16=0: f32 rows
+  static const bool res16_enabled = !(getenv("VR_ENCODE_RES16") && atoi(getenv("VR_ENCODE_RES16")) == 0);
+  const bool res16 = fold_big && res16_enabled && pp_usable(H, H) && pp_usable(H, I);
   float2* part = reinterpret_cast<float2*>(enc->lnpart);
   const int segs = H / 64;
   const unsigned fin_blocks = static_cast<unsigned>((T + 255) / 256);
@@ -2571,7 +2630,10 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       const unsigned cblocks = gblocks;
       hipLaunchKernelGGL(gather_first_rows_kernel, dim3(gblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(enc->ctx),
                          cu_dev, seq0, tok_base, n_seq, T, plain ? H / 8 : H / 4, reinterpret_cast<float4*>(ctxc));
-      if (plain)
+      if (plain && cur16)
+        hipLaunchKernelGGL(gather_first_rows_ln16_kernel, dim3(gblocks), dim3(256), 0, s, xh, cur.stat, cur.g, cur.b,
+                           cu_dev, seq0, tok_base, n_seq, T, H, xc);
+      else if (plain)
         hipLaunchKernelGGL(gather_first_rows_ln_kernel, dim3(gblocks), dim3(256), 0, s, cur.pre, cur.stat, cur.g, cur.b,
                            cu_dev, seq0, tok_base, n_seq, T, H, xc);
       else
@@ -2607,7 +2669,15 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       // hidden state = LN(cur.pre): pre-LN rows alternate between the two buffers
       float* t1 = cur.pre == enc->x ? enc->tmp : enc->x;
       float2* s1 = cur.stat == stat_b ? stat_a : stat_b;
-      if (fold_big) {
+      const bool last = li + 1 == enc->layers.size();
+      if (res16) {
+        // f16 residual stream: residual rows are f32 only in layer 0 (the embedding sum), the pre-LN rows go out
+        // as f16 into xh, in place where the residual came from there
+        VR_TRY(launch_gemm_f16x3(e, cur16 ? EPI_RLS_R16_O16 : EPI_RLS_R32_O16, ch, nullptr, w.s_o.hi, nullptr,
+                                 w.s_o.unscale, w.bo, cur16 ? reinterpret_cast<const float*>(xh) : cur.pre, nullptr, xh,
+                                 reinterpret_cast<half_t*>(part), T, H, H, 1, cur.stat, cur.g, cur.b));
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, part, T, segs, H, d.eps, s1);
+      } else if (fold_big) {
         VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN_STATS, ch, nullptr, w.s_o.hi, nullptr, w.s_o.unscale, w.bo, cur.pre,
                                  t1, xh, reinterpret_cast<half_t*>(part), T, H, H, 1, cur.stat, cur.g, cur.b));
         hipLaunchKernelGGL(ln_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, part, T, segs, H, d.eps, s1);
@@ -2633,14 +2703,17 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_GELU, xh, nullptr, w.s_1.hi, nullptr, w.s_1.unscale, w.b1, nullptr, nullptr, fh,
                                nullptr, T, I, H, 1));
-      if (fold_big)
+      if (res16)  // (the last layer of a mean-pooled model also writes f32 rows: the final LayerNorm reads them)
+        VR_TRY(launch_gemm_f16x3(e, last ? EPI_RLS_R16_O32 : EPI_RLS_R16_O16, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale,
+                                 w.b2, reinterpret_cast<const float*>(xh), last ? t2 : nullptr, xh,
+                                 reinterpret_cast<half_t*>(part), T, H, I, 1, mid.stat, mid.g, mid.b));
+      else if (fold_big)
         VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN_STATS, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre,
                                  t2, xh, reinterpret_cast<half_t*>(part), T, H, I, 1, mid.stat, mid.g, mid.b));
       else
       VR_TRY(launch_gemm_f16x3(e, EPI_BIAS_RESIDUAL_LN, fh, nullptr, w.s_2.hi, nullptr, w.s_2.unscale, w.b2, mid.pre, t2,
                                nullptr, nullptr, T, H, I, 1, mid.stat, mid.g, mid.b));
       // the last LayerNorm of the network also stores its f32 rows (into the free buffer): pooling reads them
-      const bool last = li + 1 == enc->layers.size();
       if (fold_ln && !last)
         ;  // this layer's closing LayerNorm runs inside the next layer's Q/K/V projection
       else if (fold_big && !last)  // ... its statistics only
@@ -2651,6 +2724,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       else
         hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, s, t2, T, H, w.ln2g, w.ln2b, d.eps,
                            last ? t1 : static_cast<float*>(nullptr), xh, static_cast<half_t*>(nullptr), s2);
+      cur16 = res16;
       cur = Hidden{t2, s2, w.ln2g, w.ln2b};
       if (last) final_x = t1;
       continue;

@@ -142,6 +142,8 @@ struct vr_engine {
   vr::DevArray<float> row_scale;
   int64_t stat_two_stage = 0;   // single-query dense searches served by the two-stage path
   int64_t stat_fallback = 0;    // ... of which overflowed the re-score budget and were redone one-stage
+  int64_t stat_batched = 0;         // queries served by the batched search (batch.hip)
+  int64_t stat_batch_fallback = 0;  // ... of which overflowed their candidate budget and were redone alone
   vr::DevArray<uint16_t> corpus16;
   vr::DevArray<float> row_err;
   vr::DevArray<float> upper;       // [cap_rows] upper bounds of the last prefilter pass
@@ -199,6 +201,12 @@ struct vr_engine {
   vr::DevArray<uint64_t> sp_cand;  // per-block lists of the fused sparse scan
   vr::DevArray<int32_t> q_ids;
   vr::DevArray<float> q_w;
+  // batched dense search (batch.hip): preprocessed queries, their int8 images and constants, per-slab bounds,
+  // thresholds, candidate rows / counts (+ overflow flags), exact keys (+ results)
+  vr::DevArray<float> bq_hat, bq_params, bq_best, bq_thr;
+  vr::DevArray<int32_t> bq_img, bq_cand, bq_cnt;
+  vr::DevArray<uint64_t> bq_keys;
+  vr::DevArray<float> bq_stage;  // host queries staged on the device
   // Pinned, device-mapped host scratch (1 MiB). Query inputs are written here by the host and
   // read by the kernels straight over PCIe, results are written here by the last kernel of a
   // search: the latency path of a query has no hipMemcpy at all.
@@ -239,6 +247,11 @@ int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out
 int prefilter_store_rows(vr_engine* e, int64_t n, int64_t first_row);
 bool prefilter_usable(vr_engine* e, int nq, int k);
 int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev, int32_t* out_count_dev);
+
+// ---- batch.hip: batched dense search (int8 MFMA GEMM + exact re-score)
+bool batch_usable(vr_engine* e, int nq, int k);
+int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t* mask_dev, const uint64_t** out_keys_dev,
+                 const int32_t** overflow_dev);
 
 // ---- topk.hip
 // scores: [nq][stride] f32 with -inf / masked rows excluded; result keys (descending) for each

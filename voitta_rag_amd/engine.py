@@ -130,7 +130,7 @@ class Engine:
             self.set_stream(ptr)
 
     # ---- measurement ----------------------------------------------------------------------
-    PROF_GEMM, PROF_ATTENTION, PROF_DENSE_SCAN, PROF_SPARSE_SCAN = 0, 1, 2, 3
+    PROF_GEMM, PROF_ATTENTION, PROF_DENSE_SCAN, PROF_SPARSE_SCAN, PROF_BATCH_SCAN = 0, 1, 2, 3, 4
 
     def profile(self, enable: bool) -> None:
         """HIP-event timing of the engine's kernels on its own stream (vr_profile)."""
@@ -256,7 +256,8 @@ class Engine:
     def stats(self) -> dict:
         """Counters of the two-stage dense search: searches served, overflow fallbacks, last candidate count."""
         out = {}
-        for name, which in (("two_stage", 0), ("fallback", 1), ("last_candidates", 2)):
+        for name, which in (("two_stage", 0), ("fallback", 1), ("last_candidates", 2), ("batched", 3),
+                            ("batch_fallback", 4)):
             v = C.c_int64()
             check(self._lib.vr_stats(self._h, which, C.byref(v)))
             out[name] = int(v.value)
