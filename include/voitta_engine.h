@@ -285,6 +285,14 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
                     const vr_filter* filter,
                     int64_t* rows, float* scores, int32_t* counts);
 
+/* The same search with the results left as packed ranking keys, nq x k uint64 in `keys_mem` memory (host or
+ * device): key = (order-preserving bits of the f32 score << 32) | (0xFFFFFFFF - row), descending, 0 = no result.
+ *   score bits: u = key >> 32;  f32 bits = (u & 0x80000000) ? u ^ 0x80000000 : ~u;   row = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+ * A sharded caller (voitta_rag_amd/sharded.py) hands the device array of a whole query batch straight to its
+ * RCCL all_gather — the per-shard top-k merge of SURVEY.md §8e — without a host round trip per query. */
+int vr_search_dense_keys(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k, const vr_filter* filter,
+                         uint64_t* keys, int keys_mem);
+
 /* one sparse query (host pointers): score(d) = sum_t (q_t * idf(t)) * d_t over shared terms in
  * ascending token-id order, idf(t) = ln(1 + (N - df_t + 0.5)/(df_t + 0.5)); rows sharing no
  * term are not returned. */

@@ -368,3 +368,36 @@ def test_batched_search_overflow_falls_back_per_query(gpu):
     st = e.stats()
     assert st["batched"] == nq and 2 <= st["batch_fallback"] <= 10
     e.close()
+
+
+def test_search_dense_keys_on_the_device(gpu):
+    """vr_search_dense_keys: the packed ranking keys, on the host and written straight into a device tensor (what
+    the sharded searcher hands to RCCL), decode to exactly search_dense's answer — single block and batched path."""
+    import torch
+
+    from voitta_rag_amd import Engine
+
+    rng = np.random.default_rng(31)
+    n, dim = 17000, 128
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    e = _engine(dim, initial_rows=n)
+    e.upsert(x)
+    e.delete_rows(np.arange(0, n, 9))
+    for nq in (3, 50):
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        want = e.search_dense(q, 12)
+        host = e.search_dense_keys(q, 12)
+        out = torch.zeros((nq, 12), dtype=torch.int64, device="cuda:0")
+        e.search_dense_keys(torch.from_numpy(q).to("cuda:0"), 12, out=out)
+        dev = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(host, dev)
+        rows, scores = Engine.decode_keys(host)
+        for i in range(nq):
+            assert np.array_equal(rows[i], want[i][0]) and np.array_equal(scores[i].view(np.uint32), want[i][1].view(np.uint32))
+    # fewer results than k: empty slots are key 0 -> row -1
+    small = _engine(dim)
+    small.upsert(x[:5])
+    rows, scores = Engine.decode_keys(small.search_dense_keys(x[:1], 8))
+    assert (rows[0][:5] >= 0).all() and (rows[0][5:] == -1).all()
+    small.close()
+    e.close()

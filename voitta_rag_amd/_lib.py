@@ -111,6 +111,7 @@ SIGNATURES = {
     "vr_get_dense": (C.c_int, [_vp, _i64p, C.c_int64, _fp]),
     "vr_sparse_stats": (C.c_int, [_vp, _i32p, C.c_int32, _i32p, _i64p]),
     "vr_search_dense": (C.c_int, [_vp, _vp, C.c_int32, C.c_int, C.c_int32, C.POINTER(VrFilter), _i64p, _fp, _i32p]),
+    "vr_search_dense_keys": (C.c_int, [_vp, _vp, C.c_int32, C.c_int, C.c_int32, C.POINTER(VrFilter), _vp, C.c_int]),
     "vr_search_sparse": (C.c_int, [_vp, _i32p, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(VrFilter), _i64p, _fp,
                                    _i32p]),
     "vr_idf": (C.c_float, [C.c_int64, C.c_int32]),

@@ -575,28 +575,24 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
   return 0;
 }
 
-int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k,
-                    const vr_filter* filter, int64_t* rows, float* scores, int32_t* counts) {
-  VR_TRY(check_engine(e));
-  VR_CHECK(q && rows && scores && nq >= 1, "bad arguments");
-  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
-  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+}  // extern "C"
+
+// Dense search of nq queries; the nq x k ranking keys ((order-preserving f32 score bits << 32) | ~row, descending,
+// 0 = none) go to keys_host (host array) and/or keys_dev (device array). Caller holds e->mu.
+static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int mem, int k, const vr_filter* filter,
+                                    uint64_t* keys_host, uint64_t* keys_dev) {
+  const size_t row_bytes = sizeof(uint64_t) * static_cast<size_t>(k);
   if (e->n_rows == 0) {
-    for (int64_t i = 0; i < static_cast<int64_t>(nq) * k; ++i) {
-      rows[i] = -1;
-      scores[i] = 0.0f;
-    }
-    if (counts)
-      for (int i = 0; i < nq; ++i) counts[i] = 0;
+    if (keys_host) memset(keys_host, 0, row_bytes * static_cast<size_t>(nq));
+    if (keys_dev) VR_HIP(hipMemsetAsync(keys_dev, 0, row_bytes * static_cast<size_t>(nq), e->stream));
     return 0;
   }
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
-  const uint64_t* host_keys = pin_host<uint64_t>(e, kPinDenseKeys);
-  // one 16-query block through the one-/two-stage scans; results decoded into rows/scores/counts at `at`
-  auto run_block = [&](const float* qsrc, int nb, int qmem, int at) -> int {
-    const float* q_dev = stage_query(e, qsrc, nb, qmem);
+  const uint64_t* pinned_keys = pin_host<uint64_t>(e, kPinDenseKeys);
+  // one block of <= 16 queries through the one-/two-stage scans; its keys (in the pinned result area) go to slot `at`
+  auto run_block = [&](const float* qsrc, int nb, int at) -> int {
+    const float* q_dev = stage_query(e, qsrc, nb, mem);
     bool two_stage = false;
     VR_TRY(search_dense_block(e, q_dev, nb, k, mask, true, &two_stage));
     VR_HIP(hipStreamSynchronize(e->stream));
@@ -607,17 +603,17 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
       VR_TRY(search_dense_block(e, q_dev, nb, k, mask, false));
       VR_HIP(hipStreamSynchronize(e->stream));
     }
-    for (int i = 0; i < nb; ++i) {
-      int64_t c = decode_keys(host_keys + static_cast<int64_t>(i) * k, k, rows + static_cast<int64_t>(at + i) * k,
-                              scores + static_cast<int64_t>(at + i) * k);
-      if (counts) counts[at + i] = static_cast<int32_t>(c);
+    if (keys_host) memcpy(keys_host + static_cast<size_t>(at) * k, pinned_keys, row_bytes * static_cast<size_t>(nb));
+    if (keys_dev) {
+      VR_HIP(hipMemcpyAsync(keys_dev + static_cast<size_t>(at) * k, pinned_keys, row_bytes * static_cast<size_t>(nb),
+                            hipMemcpyHostToDevice, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));  // the pinned area is reused by the next block
     }
     return 0;
   };
   if (batch_usable(e, nq, k)) {
     // many queries at once: integer GEMM over the int8 shadow + exact re-score (batch.hip), 1024 queries per round
     constexpr int kRound = 1024;
-    std::vector<uint64_t> keys(static_cast<size_t>(std::min(nq, kRound)) * k);
     std::vector<int32_t> over(static_cast<size_t>(std::min(nq, kRound)));
     for (int q0 = 0; q0 < nq; q0 += kRound) {
       const int nb = std::min(kRound, nq - q0);
@@ -628,34 +624,60 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
                               e->stream));
         q_dev = e->bq_stage.p;
       }
-      const uint64_t* keys_dev = nullptr;
+      const uint64_t* round_keys = nullptr;
       const int32_t* over_dev = nullptr;
-      VR_TRY(batch_search(e, q_dev, nb, k, mask, &keys_dev, &over_dev));
-      VR_HIP(hipMemcpyAsync(keys.data(), keys_dev, sizeof(uint64_t) * static_cast<size_t>(nb) * k, hipMemcpyDeviceToHost, e->stream));
+      VR_TRY(batch_search(e, q_dev, nb, k, mask, &round_keys, &over_dev));
+      if (keys_host)
+        VR_HIP(hipMemcpyAsync(keys_host + static_cast<size_t>(q0) * k, round_keys, row_bytes * static_cast<size_t>(nb),
+                              hipMemcpyDeviceToHost, e->stream));
+      if (keys_dev)
+        VR_HIP(hipMemcpyAsync(keys_dev + static_cast<size_t>(q0) * k, round_keys, row_bytes * static_cast<size_t>(nb),
+                              hipMemcpyDeviceToDevice, e->stream));
       VR_HIP(hipMemcpyAsync(over.data(), over_dev, sizeof(int32_t) * static_cast<size_t>(nb), hipMemcpyDeviceToHost, e->stream));
       VR_HIP(hipStreamSynchronize(e->stream));
       e->stat_batched += nb;
-      for (int i = 0; i < nb; ++i) {
+      for (int i = 0; i < nb; ++i)
         if (over[static_cast<size_t>(i)]) {  // candidate budget exceeded: this query alone, through the exact scans
           ++e->stat_batch_fallback;
-          if (mem == VR_MEM_HOST) {
-            VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, VR_MEM_HOST, q0 + i));
-          } else {
-            VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, VR_MEM_DEVICE, q0 + i));
-          }
-          continue;
+          VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, q0 + i));
         }
-        int64_t c = decode_keys(keys.data() + static_cast<int64_t>(i) * k, k, rows + static_cast<int64_t>(q0 + i) * k,
-                                scores + static_cast<int64_t>(q0 + i) * k);
-        if (counts) counts[q0 + i] = static_cast<int32_t>(c);
-      }
     }
     return 0;
   }
-  for (int q0 = 0; q0 < nq; q0 += kQueryBlock) {
-    const int nb = std::min(kQueryBlock, nq - q0);
-    VR_TRY(run_block(q + static_cast<int64_t>(q0) * e->dim, nb, mem, q0));
+  for (int q0 = 0; q0 < nq; q0 += kQueryBlock)
+    VR_TRY(run_block(q + static_cast<int64_t>(q0) * e->dim, std::min(kQueryBlock, nq - q0), q0));
+  return 0;
+}
+
+extern "C" {
+
+int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k,
+                    const vr_filter* filter, int64_t* rows, float* scores, int32_t* counts) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && rows && scores && nq >= 1, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> lock(e->mu);
+  std::vector<uint64_t> keys(static_cast<size_t>(nq) * k);
+  VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, keys.data(), nullptr));
+  for (int i = 0; i < nq; ++i) {
+    const int64_t c = decode_keys(keys.data() + static_cast<size_t>(i) * k, k, rows + static_cast<int64_t>(i) * k,
+                                  scores + static_cast<int64_t>(i) * k);
+    if (counts) counts[i] = static_cast<int32_t>(c);
   }
+  return 0;
+}
+
+int vr_search_dense_keys(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k, const vr_filter* filter,
+                         uint64_t* keys, int keys_mem) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && keys && nq >= 1, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  VR_CHECK((mem == VR_MEM_HOST || mem == VR_MEM_DEVICE) && (keys_mem == VR_MEM_HOST || keys_mem == VR_MEM_DEVICE), "bad mem");
+  std::lock_guard<std::mutex> lock(e->mu);
+  VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, keys_mem == VR_MEM_HOST ? keys : nullptr,
+                                  keys_mem == VR_MEM_DEVICE ? keys : nullptr));
+  if (keys_mem == VR_MEM_DEVICE) VR_HIP(hipStreamSynchronize(e->stream));
   return 0;
 }
 

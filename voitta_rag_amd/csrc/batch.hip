@@ -41,7 +41,6 @@ namespace vr {
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 constexpr int kBQ = 128;          // queries per block column
-constexpr int kBR = 256;          // corpus rows per block
 constexpr int kBStage = 64 * 1024;  // bytes per stage: 16 tiles x 2 kb8 KiB of rows + 8 qfrags x {a,b} x 2 kb8 KiB
 constexpr int kBatchCand = 1024;  // candidate budget per query
 constexpr int kQParams = 8;       // floats per query: a, b, |q|, |rho|, c_fixed, (3 spare)

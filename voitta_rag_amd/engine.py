@@ -326,6 +326,40 @@ class Engine:
         del keep
         return [(rows[i, : counts[i]].copy(), scores[i, : counts[i]].copy()) for i in range(nq)]
 
+    def search_dense_keys(self, queries, k: int, flt: SearchFilter | None = None, out=None):
+        """The dense search with results as packed ranking keys (include/voitta_engine.h): an (nq, k) uint64 NumPy
+        array, or — when ``out`` is an (nq, k) int64 device tensor — written there without leaving the device."""
+        if _is_device_tensor(queries):
+            self._follow(queries)
+            mem, nq = VR_MEM_DEVICE, int(queries.shape[0])
+            qp = C.c_void_p(queries.data_ptr())
+        else:
+            q = _np(queries, np.float32).reshape(-1, self.dim)
+            mem, nq = VR_MEM_HOST, q.shape[0]
+            qp = C.c_void_p(q.ctypes.data)
+        fp, keep = self._filter(flt)
+        if out is not None:
+            assert _is_device_tensor(out) and out.is_contiguous() and tuple(out.shape) == (nq, k) and out.element_size() == 8
+            self._follow(out)
+            check(self._lib.vr_search_dense_keys(self._h, qp, nq, mem, k, fp, C.c_void_p(out.data_ptr()), VR_MEM_DEVICE))
+            return out
+        keys = np.empty((nq, k), np.uint64)
+        check(self._lib.vr_search_dense_keys(self._h, qp, nq, mem, k, fp, C.c_void_p(keys.ctypes.data), VR_MEM_HOST))
+        del keep
+        return keys
+
+    @staticmethod
+    def decode_keys(keys: np.ndarray):
+        """(nq, k) uint64 keys -> (rows int64 with -1 for empty slots, scores f32)."""
+        keys = np.asarray(keys, np.uint64)
+        hi = (keys >> np.uint64(32)).astype(np.uint32)
+        bits = np.where(hi & np.uint32(0x80000000), hi ^ np.uint32(0x80000000), ~hi)
+        rows = np.int64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        rows[keys == 0] = -1
+        scores = bits.astype(np.uint32).view(np.float32).copy()
+        scores[keys == 0] = 0.0
+        return rows, scores
+
     def search_sparse(self, q_idx, q_val, k: int, flt: SearchFilter | None = None, weights_given: bool = False):
         """weights_given: q_val already holds q_t * idf_t (sharded search with global statistics)."""
         qi, qv = _np(q_idx, np.int32), _np(q_val, np.float32)
