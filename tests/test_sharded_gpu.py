@@ -34,7 +34,7 @@ def _gpu_worker(rank, world, port, ret):
         assert isinstance(store_registry.get_engine(), Engine)  # the real thing, not a double
         # a bigger shard pair for the searcher: batches == single queries == what the keys API returns
         rng = np.random.default_rng(5)
-        n, dim = 20000, 128
+        n, dim = 40000, 128  # 20000 rows per shard: above the batched search's threshold
         x = rng.standard_normal((n, dim)).astype(np.float32)
         e = Engine(dim, initial_rows=n)
         mine = np.arange(rank, n, world)
@@ -80,7 +80,7 @@ def test_two_ranks_with_real_engines_equal_one_oracle_store(gpu, monkeypatch):
         config.get_settings.cache_clear()
     # the merged dense answers of the big shard pair against one oracle scan of the whole corpus
     rng = np.random.default_rng(5)
-    n, dim = 20000, 128
+    n, dim = 40000, 128
     x = rng.standard_normal((n, dim)).astype(np.float32)
     for _ in range(n):
         rng.choice(300, size=5, replace=False), rng.uniform(0.5, 2.0, size=5)  # (keeps the generator in step)

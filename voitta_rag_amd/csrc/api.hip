@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <thread>
 
 namespace vr {
 
@@ -125,6 +126,174 @@ static int search_sparse_block(vr_engine* e, const int32_t* q_idx, const float* 
   return 0;
 }
 
+
+// ---- search lanes and the writer protocol (see vr_engine::rw) -----------------------------------------------
+
+static void release_scratch(vr_engine* e) {
+  e->upper.release();
+  e->cand_rows.release();
+  e->cand_keys.release();
+  e->stage_dense.release();
+  e->stage_len.release();
+  e->stage_off.release();
+  e->stage_idx.release();
+  e->stage_val.release();
+  e->stage_i32a.release();
+  e->stage_i32b.release();
+  e->stage_i64a.release();
+  e->stage_i64b.release();
+  e->stage_f64.release();
+  e->bm_marks.release();
+  e->bm_cnt.release();
+  e->bm_idx.release();
+  e->bm_val.release();
+  e->enc_out.release();
+  e->q_tiled.release();
+  e->scores.release();
+  e->sp_scores.release();
+  e->mask.release();
+  e->pass_folder.release();
+  e->pass_ifolder.release();
+  e->cand_a.release();
+  e->cand_b.release();
+  e->sp_cand.release();
+  e->q_ids.release();
+  e->q_w.release();
+  e->bq_hat.release();
+  e->bq_params.release();
+  e->bq_best.release();
+  e->bq_thr.release();
+  e->bq_img.release();
+  e->bq_cand.release();
+  e->bq_cnt.release();
+  e->bq_keys.release();
+  e->bq_stage.release();
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  e->pinned = nullptr;
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_input) (void)hipEventDestroy(e->ev_input);
+  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  e->ev_fork = e->ev_join = e->ev_input = nullptr;
+  e->aux_stream = e->own_stream = nullptr;
+}
+
+// the index as the master holds it right now: pointers and counts only (call with rw held)
+static void lane_view(vr_engine* L, const vr_engine* m) {
+  L->n_rows = m->n_rows;
+  L->n_live = m->n_live;
+  L->cap_rows = m->cap_rows;
+  L->corpus = m->corpus;
+  L->corpus16 = m->corpus16;
+  L->row_scale = m->row_scale;
+  L->row_err = m->row_err;
+  L->live = m->live;
+  L->folder = m->folder;
+  L->index_folder = m->index_folder;
+  L->created = m->created;
+  L->modified = m->modified;
+  L->row_slice = m->row_slice;
+  L->max_folder_id = m->max_folder_id;
+  L->max_index_folder_id = m->max_index_folder_id;
+  L->slices = m->slices;
+  L->n_slices_dev = m->n_slices_dev;
+  L->sp_idx = m->sp_idx;
+  L->sp_val = m->sp_val;
+  L->sp_used = m->sp_used;
+  L->n_sparse_points = m->n_sparse_points;
+  L->df_keys = m->df_keys;
+  L->df_cnt = m->df_cnt;
+  L->df_cap = m->df_cap;
+  L->df_bound = m->df_bound;
+  L->df_distinct = m->df_distinct;
+  L->profiler = m->profiler;
+}
+
+static vr_engine* lane_create(vr_engine* m) {
+  vr_engine* L = new vr_engine();
+  L->master = m;
+  L->device = m->device;
+  L->dim = m->dim;
+  L->kblocks = m->kblocks;
+  L->prefilter = m->prefilter;
+  L->prefilter8 = m->prefilter8;
+  bool ok = hipStreamCreateWithFlags(&L->own_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&L->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&L->ev_input, hipEventDisableTiming) == hipSuccess &&
+            hipHostMalloc(&L->pinned, kPinnedBytes, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&L->pinned_dev, L->pinned, 0) == hipSuccess;
+  if (!ok) {
+    set_error("creating a search lane failed");
+    release_scratch(L);
+    delete L;
+    return nullptr;
+  }
+  L->stream = L->own_stream;
+  L->pinned_bytes = kPinnedBytes;
+  return L;
+}
+
+// A search: takes a lane (waits for one when all are busy), the shared lock, and a fresh view of the index.
+// device_input: the caller's buffers were produced on the stream bound to the master (vr_set_stream); the lane's
+// stream is ordered behind it.
+struct SearchLane {
+  vr_engine* m;
+  vr_engine* L = nullptr;
+  std::shared_lock<std::shared_mutex> lock;
+  explicit SearchLane(vr_engine* master) : m(master) {}
+  int acquire(bool device_input) {
+    {
+      std::unique_lock<std::mutex> g(m->lane_mu);
+      while (m->lanes_free.empty() && static_cast<int>(m->lanes_all.size()) >= m->lanes_max) m->lane_cv.wait(g);
+      if (!m->lanes_free.empty()) {
+        L = m->lanes_free.back();
+        m->lanes_free.pop_back();
+      } else {
+        L = lane_create(m);
+        if (!L) return -1;
+        m->lanes_all.push_back(L);
+      }
+    }
+    while (m->writers_waiting.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    lock = std::shared_lock<std::shared_mutex>(m->rw);
+    lane_view(L, m);
+    if (device_input) {
+      if (hipEventRecord(L->ev_input, m->stream) != hipSuccess || hipStreamWaitEvent(L->stream, L->ev_input, 0) != hipSuccess) {
+        set_error("ordering the search behind the caller's stream failed");
+        return -1;
+      }
+    }
+    return 0;
+  }
+  ~SearchLane() {
+    if (!L) return;
+    m->stat_two_stage += L->stat_two_stage.exchange(0);
+    m->stat_fallback += L->stat_fallback.exchange(0);
+    m->stat_batched += L->stat_batched.exchange(0);
+    m->stat_batch_fallback += L->stat_batch_fallback.exchange(0);
+    if (lock.owns_lock()) lock.unlock();
+    {
+      std::lock_guard<std::mutex> g(m->lane_mu);
+      m->lanes_free.push_back(L);
+    }
+    m->lane_cv.notify_one();
+  }
+};
+
+// A mutation publishes under the exclusive lock; searches that are already running finish first, new ones wait.
+struct PublishLock {
+  vr_engine* e;
+  std::unique_lock<std::shared_mutex> lock;
+  explicit PublishLock(vr_engine* eng) : e(eng) {
+    e->writers_waiting.fetch_add(1, std::memory_order_acq_rel);
+    lock = std::unique_lock<std::shared_mutex>(e->rw);
+    e->writers_waiting.fetch_sub(1, std::memory_order_acq_rel);
+  }
+};
+
 }  // namespace vr
 
 using namespace vr;
@@ -187,6 +356,7 @@ int vr_engine_create(const vr_config* cfg, vr_engine** out) {
     return -1;
   }
   e->pinned_bytes = kPinnedBytes;
+  if (const char* lanes = getenv("VR_SEARCH_LANES")) e->lanes_max = std::min(16, std::max(1, atoi(lanes)));
   int64_t init = cfg->initial_rows > 0 ? cfg->initial_rows : 1024;
   if (ensure_rows(e, init) != 0) {
     vr_engine_destroy(e);
@@ -206,9 +376,13 @@ void vr_engine_destroy(vr_engine* e) {
   e->corpus16.release();
   e->row_err.release();
   e->row_scale.release();
-  e->upper.release();
-  e->cand_rows.release();
-  e->cand_keys.release();
+  for (vr_engine* L : e->lanes_all) {
+    if (L->own_stream) (void)hipStreamSynchronize(L->own_stream);
+    release_scratch(L);
+    delete L;
+  }
+  e->lanes_all.clear();
+  e->lanes_free.clear();
   e->live.release();
   e->folder.release();
   e->index_folder.release();
@@ -221,46 +395,7 @@ void vr_engine_destroy(vr_engine* e) {
   e->df_keys.release();
   e->df_cnt.release();
   if (e->df_distinct) (void)hipFree(e->df_distinct);
-  e->stage_dense.release();
-  e->stage_len.release();
-  e->stage_off.release();
-  e->stage_idx.release();
-  e->stage_val.release();
-  e->stage_i32a.release();
-  e->stage_i32b.release();
-  e->stage_i64a.release();
-  e->stage_i64b.release();
-  e->stage_f64.release();
-  e->bm_marks.release();
-  e->bm_cnt.release();
-  e->bm_idx.release();
-  e->bm_val.release();
-  e->enc_out.release();
-  e->q_tiled.release();
-  e->scores.release();
-  e->sp_scores.release();
-  e->mask.release();
-  e->pass_folder.release();
-  e->pass_ifolder.release();
-  e->cand_a.release();
-  e->cand_b.release();
-  e->sp_cand.release();
-  e->q_ids.release();
-  e->q_w.release();
-  e->bq_hat.release();
-  e->bq_params.release();
-  e->bq_best.release();
-  e->bq_thr.release();
-  e->bq_img.release();
-  e->bq_cand.release();
-  e->bq_cnt.release();
-  e->bq_keys.release();
-  e->bq_stage.release();
-  if (e->pinned) (void)hipHostFree(e->pinned);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
-  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  release_scratch(e);
   delete e;
 }
 

@@ -7,8 +7,11 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -123,7 +126,24 @@ struct vr_engine {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_join = nullptr;
-  std::mutex mu;
+  // Concurrency (callers: MCP worker threads search while the indexing thread, the watcher
+  // and the event loop mutate — watcher.py:149-171, indexing.py:281-288, api/routes/folders.py:137-143):
+  //   rw       searches hold it SHARED for their whole duration; a mutation holds it EXCLUSIVELY only while it
+  //            publishes (appends rows, sets tombstones, swaps in a compacted index)
+  //   wmu      one writer (or encoder call) at a time; they share the master's stream and scratch
+  //   lanes    a search runs on a LANE: a private vr_engine that owns its stream, pinned staging area and scratch
+  //            arrays and holds a VIEW (pointers + counts, refreshed under the shared lock) of the master's index —
+  //            so several searches run at once, each on its own HIP stream, over the same HBM-resident tables.
+  std::shared_mutex rw;
+  std::mutex wmu;
+  std::atomic<int> writers_waiting{0};  // searches let a waiting writer in first (shared_mutex prefers readers)
+  std::mutex lane_mu;
+  std::condition_variable lane_cv;
+  std::vector<vr_engine*> lanes_free;
+  std::vector<vr_engine*> lanes_all;
+  int lanes_max = 4;
+  vr_engine* master = nullptr;  // set in a lane
+  hipEvent_t ev_input = nullptr;  // lane: orders its stream behind the master's bound stream (device inputs)
 
   int64_t n_rows = 0;
   int64_t n_live = 0;
@@ -140,10 +160,12 @@ struct vr_engine {
   // row_err the exact residual |x - scale * int8(x)|_2. Half the bytes of the f16 shadow again.
   bool prefilter8 = false;
   vr::DevArray<float> row_scale;
-  int64_t stat_two_stage = 0;   // single-query dense searches served by the two-stage path
-  int64_t stat_fallback = 0;    // ... of which overflowed the re-score budget and were redone one-stage
-  int64_t stat_batched = 0;         // queries served by the batched search (batch.hip)
-  int64_t stat_batch_fallback = 0;  // ... of which overflowed their candidate budget and were redone alone
+  // (a lane counts for itself; its counts are added to the master's when it is handed back)
+  std::atomic<int64_t> stat_two_stage{0};       // single-query dense searches served by the two-stage path
+  std::atomic<int64_t> stat_fallback{0};        // ... of which overflowed the re-score budget and were redone one-stage
+  std::atomic<int64_t> stat_batched{0};         // queries served by the batched search (batch.hip)
+  std::atomic<int64_t> stat_batch_fallback{0};  // ... of which overflowed their candidate budget and were redone alone
+  std::atomic<int64_t> stat_last_candidates{0}; // rows re-scored by the last two-stage search
   vr::DevArray<uint16_t> corpus16;
   vr::DevArray<float> row_err;
   vr::DevArray<float> upper;       // [cap_rows] upper bounds of the last prefilter pass
