@@ -21,8 +21,15 @@
  *     Output buffers follow the same `mem` unless stated otherwise.
  *   - row ids are dense int64 indices into the engine's HBM-resident tables, assigned in upsert
  *     order; the UUID<->row map and the text payload stay in the Python host.
- *   - thread-safety: one engine may be called from any number of threads; calls are serialised by
- *     an internal mutex (kernels of one call run back-to-back on the engine's HIP stream).
+ *   - thread-safety: one engine may be called from any number of threads. Searches run CONCURRENTLY, each on
+ *     its own HIP stream with its own staging area ("lanes", VR_SEARCH_LANES of them, default 4; further
+ *     searches wait for a free one), and hold a shared lock on the index for their duration. Mutations
+ *     (vr_upsert, vr_index_batch, vr_delete_rows, vr_compact, vr_load) and vr_encode are serialised among
+ *     themselves and take the exclusive lock only to PUBLISH: the append of a batch, the tombstones of a
+ *     delete, the pointer swap of a compaction (which builds its result beside the live index). A search
+ *     therefore sees the state before or after a mutation, never a mixture, and waits for no encode and
+ *     no compaction (the reference's callers: watcher.py:149-171,
+ *     indexing.py:281-288, api/routes/folders.py:137-143 beside MCP search threads).
  *   - there is NO CPU fallback: creating an engine without a usable gfx950 device fails.
  */
 #ifndef VOITTA_ENGINE_H
@@ -261,6 +268,8 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
 #define VR_STAT_LAST_CANDIDATES 2  /* rows re-scored by the last two-stage search */
 #define VR_STAT_BATCHED 3          /* queries served by the batched (integer GEMM) dense search */
 #define VR_STAT_BATCH_FALLBACK 4   /* ... of which exceeded their candidate budget and were redone alone */
+#define VR_STAT_GENERATION 5       /* bumped whenever row numbers change meaning (vr_compact, vr_load): a host
+                                      table keyed by row is valid for the generation it was built against */
 int vr_stats(vr_engine* e, int32_t which, int64_t* out);
 
 /* n_rows = rows ever assigned, n_live = not tombstoned (get_collection_info, vector_store.py:699-710) */
@@ -344,7 +353,8 @@ int vr_save(vr_engine* e, const char* path);
  *   new_row_of_old  host int64[rows before the call] (may be NULL): new row, or -1 for a dropped row
  *   n_rows_after    rows (= live rows) after the call
  * Scores and rankings are unchanged (document frequencies and the sparse point count never
- * included deleted rows). Runs under the engine's mutex: searches wait, none sees a partial state. */
+ * included deleted rows). The compacted tables are built beside the live ones; searches keep running
+ * and only wait for the final exchange of pointers. VR_STAT_GENERATION is bumped by that exchange. */
 int vr_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after);
 int vr_load(vr_engine* e, const char* path);
 

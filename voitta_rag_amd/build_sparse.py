@@ -43,7 +43,7 @@ def build_sparse_vectors(batch_size: int = 500, insert_batch_size: int = 100, ta
     col = vs._col
     stats = {"source": source, "target": target, "processed": 0, "inserted": 0, "skipped": 0, "errors": 0,
              "elapsed": 0.0, "rate": 0.0}
-    with col.lock:
+    with col.write_lock, col.lock:  # (an offline tool: no mutation and no host-table change while it copies)
         rows = np.fromiter(col.live_rows(), dtype=np.int64)
         total_points = int(rows.size)
         logger.info("Source: %s  Target: %s  Points: %d  Dense dim: %d", source, target, total_points, vs.dimension)

@@ -233,6 +233,7 @@ static vr_engine* lane_create(vr_engine* m) {
   }
   L->stream = L->own_stream;
   L->pinned_bytes = kPinnedBytes;
+  L->stat_last_candidates.store(-1);
   return L;
 }
 
@@ -274,23 +275,14 @@ struct SearchLane {
     m->stat_fallback += L->stat_fallback.exchange(0);
     m->stat_batched += L->stat_batched.exchange(0);
     m->stat_batch_fallback += L->stat_batch_fallback.exchange(0);
+    const int64_t lc = L->stat_last_candidates.exchange(-1);
+    if (lc >= 0) m->stat_last_candidates.store(lc);
     if (lock.owns_lock()) lock.unlock();
     {
       std::lock_guard<std::mutex> g(m->lane_mu);
       m->lanes_free.push_back(L);
     }
     m->lane_cv.notify_one();
-  }
-};
-
-// A mutation publishes under the exclusive lock; searches that are already running finish first, new ones wait.
-struct PublishLock {
-  vr_engine* e;
-  std::unique_lock<std::shared_mutex> lock;
-  explicit PublishLock(vr_engine* eng) : e(eng) {
-    e->writers_waiting.fetch_add(1, std::memory_order_acq_rel);
-    lock = std::unique_lock<std::shared_mutex>(e->rw);
-    e->writers_waiting.fetch_sub(1, std::memory_order_acq_rel);
   }
 };
 
@@ -409,7 +401,7 @@ void* vr_stream(vr_engine* e) { return e ? static_cast<void*>(e->stream) : nullp
 
 int vr_set_stream(vr_engine* e, void* stream) {
   VR_TRY(check_engine(e));
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
   VR_HIP(hipStreamSynchronize(e->stream));
   e->stream = stream ? static_cast<hipStream_t>(stream) : e->own_stream;
   return 0;
@@ -420,7 +412,7 @@ int vr_encoder_load(vr_engine* e, const vr_bert_desc* desc, const void* const* t
   VR_TRY(check_engine(e));
   VR_CHECK(desc && tensors, "null argument");
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
   return encoder_load(e, desc, tensors, n_tensors, mem);
 }
 
@@ -430,13 +422,13 @@ int vr_encode(vr_engine* e, const int32_t* ids, const int32_t* offsets, int32_t 
   VR_CHECK(n_seq >= 0 && (n_seq == 0 || (ids && offsets && out)), "bad arguments");
   VR_CHECK((mem == VR_MEM_HOST || mem == VR_MEM_DEVICE) && (out_mem == VR_MEM_HOST || out_mem == VR_MEM_DEVICE),
            "bad mem");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
   return encoder_encode(e, ids, offsets, n_seq, mem, out, out_mem);
 }
 
 }  // extern "C"
 
-// Body of vr_upsert, also the last stage of vr_index_batch. Caller holds e->mu.
+// Body of vr_upsert, also the last stage of vr_index_batch. Caller holds e->wmu and the exclusive lock.
 // sp_cnt_dev (device memory, mem == VR_MEM_DEVICE only): when given, the sparse rows are in the
 // padded layout bm25_tf_kernel writes — row r = idx/val[sp_off[r] .. sp_off[r] + sp_cnt_dev[r]).
 static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, const int64_t* sp_off,
@@ -578,7 +570,8 @@ int vr_upsert(vr_engine* e, int64_t n, int mem, const float* dense, const int64_
   VR_TRY(check_engine(e));
   VR_CHECK(n >= 0, "negative row count");
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  PublishLock publish(e);  // (the append itself: a fraction of a millisecond per thousand rows)
   return upsert_locked(e, n, mem, dense, sp_off, sp_idx, sp_val, nullptr, folder_id, index_folder_id,
                        created, modified, out_first_row);
 }
@@ -591,7 +584,7 @@ int vr_index_batch(vr_engine* e, int64_t n, int mem, const int32_t* wp_ids, cons
   VR_CHECK(n >= 0 && (n == 0 || (wp_ids && wp_off)), "bad arguments");
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
   VR_CHECK((bm_ids == nullptr) == (bm_off == nullptr), "bm_ids and bm_off go together");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
   if (n == 0) {
     if (out_first_row) *out_first_row = e->n_rows;
     return 0;
@@ -630,7 +623,8 @@ int vr_index_batch(vr_engine* e, int64_t n, int mem, const int32_t* wp_ids, cons
   VR_CHECK(encoder_hidden(e) == e->dim, "encoder width %d != store dimension %d", encoder_hidden(e), e->dim);
   VR_TRY(e->enc_out.grow(n * e->dim, 0, e->stream));
   VR_TRY(encoder_encode(e, wp_ids, wp_off, static_cast<int>(n), mem, e->enc_out.p, VR_MEM_DEVICE));
-  // 3. store
+  // 3. store: the only part searches wait for (they ran beside the encode)
+  PublishLock publish(e);
   return upsert_locked(e, n, VR_MEM_DEVICE, e->enc_out.p, bm_off_dev, bm_off ? e->bm_idx.p : nullptr,
                        bm_off ? e->bm_val.p : nullptr, bm_off ? e->bm_cnt.p : nullptr, folder_id,
                        index_folder_id, created, modified, out_first_row);
@@ -640,7 +634,8 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n) {
   VR_TRY(check_engine(e));
   VR_CHECK(n >= 0 && (n == 0 || rows), "bad arguments");
   if (n == 0) return 0;
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  PublishLock publish(e);
   std::vector<int64_t> uniq(rows, rows + n);
   std::sort(uniq.begin(), uniq.end());
   uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -657,13 +652,13 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n) {
 
 int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
   VR_CHECK(e != nullptr && out != nullptr, "null argument");
-  std::lock_guard<std::mutex> lock(e->mu);
   switch (which) {
-    case VR_STAT_TWO_STAGE: *out = e->stat_two_stage; break;
-    case VR_STAT_FALLBACK: *out = e->stat_fallback; break;
-    case VR_STAT_LAST_CANDIDATES: *out = *pin_host<int32_t>(e, kPinCandCount); break;
-    case VR_STAT_BATCHED: *out = e->stat_batched; break;
-    case VR_STAT_BATCH_FALLBACK: *out = e->stat_batch_fallback; break;
+    case VR_STAT_TWO_STAGE: *out = e->stat_two_stage.load(); break;
+    case VR_STAT_FALLBACK: *out = e->stat_fallback.load(); break;
+    case VR_STAT_LAST_CANDIDATES: *out = e->stat_last_candidates.load(); break;
+    case VR_STAT_BATCHED: *out = e->stat_batched.load(); break;
+    case VR_STAT_BATCH_FALLBACK: *out = e->stat_batch_fallback.load(); break;
+    case VR_STAT_GENERATION: *out = e->generation.load(); break;
     default: set_error("unknown statistic %d", which); return -1;
   }
   return 0;
@@ -671,7 +666,7 @@ int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
 
 int vr_count(vr_engine* e, int64_t* n_rows, int64_t* n_live) {
   VR_CHECK(e != nullptr, "null engine");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::shared_lock<std::shared_mutex> view(e->rw);
   if (n_rows) *n_rows = e->n_rows;
   if (n_live) *n_live = e->n_live;
   return 0;
@@ -681,7 +676,8 @@ int vr_get_dense(vr_engine* e, const int64_t* rows, int64_t n, float* out) {
   VR_TRY(check_engine(e));
   VR_CHECK(n >= 0 && (n == 0 || (rows && out)), "bad arguments");
   if (n == 0) return 0;
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);  // (the master's staging arrays)
+  std::shared_lock<std::shared_mutex> view(e->rw);
   for (int64_t i = 0; i < n; ++i)
     VR_CHECK(rows[i] >= 0 && rows[i] < e->n_rows, "row %lld out of range", static_cast<long long>(rows[i]));
   VR_TRY(e->stage_i64a.grow(n, 0, e->stream));
@@ -697,7 +693,8 @@ int vr_get_dense(vr_engine* e, const int64_t* rows, int64_t n, float* out) {
 
 int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df, int64_t* out_n_points) {
   VR_TRY(check_engine(e));
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  std::shared_lock<std::shared_mutex> view(e->rw);
   if (out_n_points) *out_n_points = e->n_sparse_points;
   if (n > 0) {
     VR_CHECK(ids && out_df, "null argument");
@@ -713,7 +710,7 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 }  // extern "C"
 
 // Dense search of nq queries; the nq x k ranking keys ((order-preserving f32 score bits << 32) | ~row, descending,
-// 0 = none) go to keys_host (host array) and/or keys_dev (device array). Caller holds e->mu.
+// 0 = none) go to keys_host (host array) and/or keys_dev (device array). `e` is a search lane (SearchLane).
 static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int mem, int k, const vr_filter* filter,
                                     uint64_t* keys_host, uint64_t* keys_dev) {
   const size_t row_bytes = sizeof(uint64_t) * static_cast<size_t>(k);
@@ -732,6 +729,7 @@ static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int me
     VR_TRY(search_dense_block(e, q_dev, nb, k, mask, true, &two_stage));
     VR_HIP(hipStreamSynchronize(e->stream));
     e->stat_two_stage += two_stage;
+    if (two_stage) e->stat_last_candidates.store(*pin_host<int32_t>(e, kPinCandCount));
     if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
       // more candidates than the re-score budget (near-duplicate corpus): one-stage exact scan
       ++e->stat_fallback;
@@ -792,9 +790,10 @@ int vr_search_dense(vr_engine* e, const float* q, int32_t nq, int mem, int32_t k
   VR_CHECK(q && rows && scores && nq >= 1, "bad arguments");
   VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(mem == VR_MEM_DEVICE));
   std::vector<uint64_t> keys(static_cast<size_t>(nq) * k);
-  VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, keys.data(), nullptr));
+  VR_TRY(search_dense_keys_locked(lane.L, q, nq, mem, k, filter, keys.data(), nullptr));
   for (int i = 0; i < nq; ++i) {
     const int64_t c = decode_keys(keys.data() + static_cast<size_t>(i) * k, k, rows + static_cast<int64_t>(i) * k,
                                   scores + static_cast<int64_t>(i) * k);
@@ -809,10 +808,11 @@ int vr_search_dense_keys(vr_engine* e, const float* q, int32_t nq, int mem, int3
   VR_CHECK(q && keys && nq >= 1, "bad arguments");
   VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
   VR_CHECK((mem == VR_MEM_HOST || mem == VR_MEM_DEVICE) && (keys_mem == VR_MEM_HOST || keys_mem == VR_MEM_DEVICE), "bad mem");
-  std::lock_guard<std::mutex> lock(e->mu);
-  VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, keys_mem == VR_MEM_HOST ? keys : nullptr,
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(true));  // (device output: ordered behind the caller's stream either way)
+  VR_TRY(search_dense_keys_locked(lane.L, q, nq, mem, k, filter, keys_mem == VR_MEM_HOST ? keys : nullptr,
                                   keys_mem == VR_MEM_DEVICE ? keys : nullptr));
-  if (keys_mem == VR_MEM_DEVICE) VR_HIP(hipStreamSynchronize(e->stream));
+  if (keys_mem == VR_MEM_DEVICE) VR_HIP(hipStreamSynchronize(lane.L->stream));
   return 0;
 }
 
@@ -822,7 +822,11 @@ int vr_search_sparse(vr_engine* e, const int32_t* q_idx, const float* q_val, int
   VR_TRY(check_engine(e));
   VR_CHECK(rows && scores && count, "bad arguments");
   VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
-  std::lock_guard<std::mutex> lock(e->mu);
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(false));
+  vr_engine* m = e;
+  e = lane.L;  // everything below runs on the lane: its stream, its scratch, its view of the index
+  (void)m;
   *count = 0;
   for (int i = 0; i < k; ++i) {
     rows[i] = -1;
@@ -848,7 +852,9 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   VR_CHECK(limit >= 1 && limit * 3 <= kMaxK, "limit = %d not in 1..%d", limit, kMaxK / 3);
   VR_CHECK(fusion == VR_FUSION_MINMAX || fusion == VR_FUSION_RRF, "unknown fusion %d", fusion);
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
-  std::lock_guard<std::mutex> lock(e->mu);
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(mem == VR_MEM_DEVICE));
+  e = lane.L;  // everything below runs on the lane: its stream, its scratch, its view of the index
   *out_count = 0;
   if (e->n_rows == 0) return 0;
   const int k = limit * 3;  // prefetch_limit, vector_store.py:636
@@ -881,6 +887,7 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   }
   VR_HIP(hipStreamSynchronize(e->stream));
   e->stat_two_stage += two_stage;
+  if (two_stage) e->stat_last_candidates.store(*pin_host<int32_t>(e, kPinCandCount));
   if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
     ++e->stat_fallback;
     VR_TRY(search_dense_block(e, q_dev, 1, k, mask, false));  // candidate overflow: one-stage exact scan
@@ -899,22 +906,26 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
 
 int vr_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after) {
   VR_TRY(check_engine(e));
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);  // (engine_compact takes the exclusive lock itself, for the swap only)
   return engine_compact(e, new_row_of_old, n_rows_after);
 }
 
 int vr_save(vr_engine* e, const char* path) {
   VR_TRY(check_engine(e));
   VR_CHECK(path && *path, "null path");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  std::shared_lock<std::shared_mutex> view(e->rw);
   return engine_save(e, path);
 }
 
 int vr_load(vr_engine* e, const char* path) {
   VR_TRY(check_engine(e));
   VR_CHECK(path && *path, "null path");
-  std::lock_guard<std::mutex> lock(e->mu);
-  return engine_load(e, path);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  PublishLock publish(e);
+  const int rc = engine_load(e, path);
+  if (rc == 0) e->generation.fetch_add(1);
+  return rc;
 }
 
 int vr_fuse_minmax(const int64_t* d_rows, const float* d_scores, int32_t nd, const int64_t* s_rows,

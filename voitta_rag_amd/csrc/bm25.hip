@@ -121,7 +121,7 @@ extern "C" int vr_bm25_tf(vr_engine* e, const int64_t* tok_off, const int32_t* t
   VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
   VR_CHECK(avg_len > 0.0, "avg_len must be positive");
   if (n_docs == 0) return 0;
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> lock(e->wmu);
   if (mem == VR_MEM_DEVICE) {
     int64_t n_tokens = 0;
     VR_HIP(hipMemcpyAsync(&n_tokens, tok_off + n_docs, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));

@@ -83,20 +83,20 @@ __global__ void restore_no_sparse_kernel(const uint8_t* __restrict__ has_sparse,
 }
 
 template <class T>
-int gather_column(vr_engine* e, DevArray<T>& col, const int32_t* old_of_new, int64_t n_new) {
-  DevArray<T> fresh;
-  VR_TRY(fresh.grow(col.cap, 0, e->stream));
+int gather_column(hipStream_t s, const DevArray<T>& src, DevArray<T>& dst, const int32_t* old_of_new, int64_t n_new) {
   if (n_new > 0)
-    hipLaunchKernelGGL((gather_column_kernel<T>), dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, e->stream,
-                       col.p, old_of_new, n_new, fresh.p);
-  VR_HIP(hipStreamSynchronize(e->stream));
-  col.release();
-  col = fresh;
+    hipLaunchKernelGGL((gather_column_kernel<T>), dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, s, src.p,
+                       old_of_new, n_new, dst.p);
   return 0;
 }
 
 }  // namespace
 
+// The compacted index is built BESIDE the live one, in a shadow engine that shares nothing with it but the
+// document-frequency table (deleted rows never counted there, so it is the same before and after): searches keep
+// running on the old tables the whole time. Only the final exchange of pointers and counts happens under the
+// exclusive lock — the "compaction into a shadow + swap" of a store that is mutated while it serves (Qdrant's
+// optimiser does the same with segments in the background). The caller holds e->wmu: no other writer exists.
 int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after) {
   VR_HIP(hipStreamSynchronize(e->stream));
   const int64_t n_old = e->n_rows;
@@ -115,11 +115,45 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
   if (n_rows_after) *n_rows_after = n_new;
   if (n_new == n_old) return 0;  // nothing to reclaim
   hipStream_t s = e->stream;
+
+  vr_engine t;  // the shadow
+  t.device = e->device;
+  t.dim = e->dim;
+  t.kblocks = e->kblocks;
+  t.prefilter = e->prefilter;
+  t.prefilter8 = e->prefilter8;
+  t.stream = s;  // (the master's stream: searches run on their lanes' streams)
+  auto fail = [&](int rc) {
+    (void)hipStreamSynchronize(s);
+    t.corpus.release();
+    t.corpus16.release();
+    t.row_err.release();
+    t.row_scale.release();
+    t.live.release();
+    t.folder.release();
+    t.index_folder.release();
+    t.created.release();
+    t.modified.release();
+    t.row_slice.release();
+    t.slices.release();
+    t.sp_idx.release();
+    t.sp_val.release();
+    t.stage_i32a.release();
+    t.stage_i32b.release();
+    return rc;
+  };
+#define VR_CTRY(expr)                  \
+  do {                                 \
+    const int rc_ = (expr);            \
+    if (rc_ != 0) return fail(rc_);    \
+  } while (0)
+  VR_CTRY(ensure_rows(&t, std::max<int64_t>(e->cap_rows, 1024)));  // same capacity: later appends find the room they had
+
   DevArray<int32_t> map;
-  VR_TRY(map.grow(std::max<int64_t>(n_new, 1), 0, s));
+  VR_CTRY(map.grow(std::max<int64_t>(n_new, 1), 0, s));
   if (n_new) VR_HIP(hipMemcpyAsync(map.p, old_of_new.data(), sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyHostToDevice, s));
 
-  // ---- sparse rows out of the old slices, into a temporary CSR (before row_slice is re-packed)
+  // ---- sparse rows out of the old slices, into a temporary CSR
   DevArray<int32_t> cnt, tmp_idx;
   DevArray<float> tmp_val;
   DevArray<int64_t> begin;
@@ -129,55 +163,70 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
   const bool any_sparse = !e->slices_host.empty() && n_new > 0;
   if (any_sparse) {
     const unsigned blocks = static_cast<unsigned>((n_new + 255) / 256);
-    VR_TRY(cnt.grow(n_new, 0, s));
+    VR_CTRY(cnt.grow(n_new, 0, s));
     hipLaunchKernelGGL(count_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
                        e->sp_idx.p, cnt.p);
     VR_HIP(hipMemcpyAsync(cnt_host.data(), cnt.p, sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyDeviceToHost, s));
     VR_HIP(hipStreamSynchronize(s));
     for (int64_t i = 0; i < n_new; ++i) begin_host[static_cast<size_t>(i) + 1] = begin_host[static_cast<size_t>(i)] + cnt_host[static_cast<size_t>(i)];
     const int64_t nnz = begin_host.back();
-    VR_TRY(begin.grow(n_new + 1, 0, s));
-    VR_TRY(tmp_idx.grow(std::max<int64_t>(nnz, 1), 0, s));
-    VR_TRY(tmp_val.grow(std::max<int64_t>(nnz, 1), 0, s));
-    VR_TRY(has_sparse.grow(n_new, 0, s));
+    VR_CTRY(begin.grow(n_new + 1, 0, s));
+    VR_CTRY(tmp_idx.grow(std::max<int64_t>(nnz, 1), 0, s));
+    VR_CTRY(tmp_val.grow(std::max<int64_t>(nnz, 1), 0, s));
+    VR_CTRY(has_sparse.grow(n_new, 0, s));
     VR_HIP(hipMemcpyAsync(begin.p, begin_host.data(), sizeof(int64_t) * (static_cast<size_t>(n_new) + 1), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(extract_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
                        e->sp_idx.p, e->sp_val.p, begin.p, tmp_idx.p, tmp_val.p, has_sparse.p);
-    VR_HIP(hipStreamSynchronize(s));
   }
 
-  // ---- dense image and payload columns
-  {
-    DevArray<float> fresh;
-    VR_TRY(fresh.grow(e->corpus.cap, 0, s));
-    if (n_new)
-      hipLaunchKernelGGL(gather_dense_kernel, dim3(static_cast<unsigned>((n_new + 3) / 4)), dim3(256), 0, s, e->corpus.p, map.p,
-                         n_new, e->dim, e->kblocks, fresh.p);
-    VR_HIP(hipStreamSynchronize(s));
-    e->corpus.release();
-    e->corpus = fresh;
-  }
-  VR_TRY(gather_column(e, e->folder, map.p, n_new));
-  VR_TRY(gather_column(e, e->index_folder, map.p, n_new));
-  VR_TRY(gather_column(e, e->created, map.p, n_new));
-  VR_TRY(gather_column(e, e->modified, map.p, n_new));
-  VR_HIP(hipMemsetAsync(e->live.p, 1, static_cast<size_t>(n_new), s));
-  VR_HIP(hipMemsetAsync(e->live.p + n_new, 0, static_cast<size_t>(e->cap_rows - n_new), s));
-  VR_HIP(hipMemsetAsync(e->row_slice.p, 0xFF, sizeof(int32_t) * static_cast<size_t>(e->cap_rows), s));  // -1
+  // ---- dense image and payload columns, gathered into the shadow
+  if (n_new)
+    hipLaunchKernelGGL(gather_dense_kernel, dim3(static_cast<unsigned>((n_new + 3) / 4)), dim3(256), 0, s, e->corpus.p, map.p,
+                       n_new, e->dim, e->kblocks, t.corpus.p);
+  VR_CTRY(gather_column(s, e->folder, t.folder, map.p, n_new));
+  VR_CTRY(gather_column(s, e->index_folder, t.index_folder, map.p, n_new));
+  VR_CTRY(gather_column(s, e->created, t.created, map.p, n_new));
+  VR_CTRY(gather_column(s, e->modified, t.modified, map.p, n_new));
+  VR_HIP(hipMemsetAsync(t.live.p, 1, static_cast<size_t>(n_new), s));  // (ensure_rows zeroed the rest)
+  VR_HIP(hipMemsetAsync(t.row_slice.p, 0xFF, sizeof(int32_t) * static_cast<size_t>(t.cap_rows), s));  // -1
 
-  // ---- sparse index re-packed in the new row order; df table and point count stay as they are
-  e->slices_host.clear();
-  e->n_slices_dev = 0;
-  e->sp_used = 0;
-  e->n_rows = n_new;
+  // ---- sparse index re-packed in the new row order; the df table and the point count carry over as they are
+  t.n_rows = n_new;
+  t.n_live = n_new;
   if (any_sparse) {
-    VR_TRY(sparse_append(e, n_new, 0, cnt_host.data(), begin.p, nullptr, tmp_idx.p, tmp_val.p, /*account=*/false));
+    VR_CTRY(sparse_append(&t, n_new, 0, cnt_host.data(), begin.p, nullptr, tmp_idx.p, tmp_val.p, /*account=*/false));
     hipLaunchKernelGGL(restore_no_sparse_kernel, dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, s,
-                       has_sparse.p, n_new, e->row_slice.p);
+                       has_sparse.p, n_new, t.row_slice.p);
   }
-  VR_TRY(prefilter_store_rows(e, n_new, 0));
+  VR_CTRY(prefilter_store_rows(&t, n_new, 0));
   VR_HIP(hipStreamSynchronize(s));
   VR_HIP(hipGetLastError());
+#undef VR_CTRY
+
+  {  // ---- the swap: the only moment searches wait for
+    PublishLock publish(e);
+    std::swap(e->corpus, t.corpus);
+    std::swap(e->corpus16, t.corpus16);
+    std::swap(e->row_err, t.row_err);
+    std::swap(e->row_scale, t.row_scale);
+    std::swap(e->live, t.live);
+    std::swap(e->folder, t.folder);
+    std::swap(e->index_folder, t.index_folder);
+    std::swap(e->created, t.created);
+    std::swap(e->modified, t.modified);
+    std::swap(e->row_slice, t.row_slice);
+    std::swap(e->slices, t.slices);
+    std::swap(e->sp_idx, t.sp_idx);
+    std::swap(e->sp_val, t.sp_val);
+    e->slices_host.swap(t.slices_host);
+    e->n_slices_dev = t.n_slices_dev;
+    e->sp_used = t.sp_used;
+    e->cap_rows = t.cap_rows;
+    e->n_rows = n_new;
+    e->n_live = n_new;
+    e->generation.fetch_add(1);
+  }
+  fail(0);  // what the shadow holds now is the old index: release it (no search can still be reading it)
   map.release();
   cnt.release();
   tmp_idx.release();

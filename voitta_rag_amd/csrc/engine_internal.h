@@ -166,6 +166,7 @@ struct vr_engine {
   std::atomic<int64_t> stat_batched{0};         // queries served by the batched search (batch.hip)
   std::atomic<int64_t> stat_batch_fallback{0};  // ... of which overflowed their candidate budget and were redone alone
   std::atomic<int64_t> stat_last_candidates{0}; // rows re-scored by the last two-stage search
+  std::atomic<int64_t> generation{0};           // bumped whenever row numbers change (vr_compact's swap, vr_load)
   vr::DevArray<uint16_t> corpus16;
   vr::DevArray<float> row_err;
   vr::DevArray<float> upper;       // [cap_rows] upper bounds of the last prefilter pass
@@ -242,6 +243,18 @@ struct vr_engine {
 
 
 namespace vr {
+
+// A mutation publishes under the exclusive lock: searches that are already running finish first, new ones wait
+// (they yield while writers_waiting > 0 — a shared_mutex prefers readers and would starve the writer).
+struct PublishLock {
+  vr_engine* e;
+  std::unique_lock<std::shared_mutex> lock;
+  explicit PublishLock(vr_engine* eng) : e(eng) {
+    e->writers_waiting.fetch_add(1, std::memory_order_acq_rel);
+    lock = std::unique_lock<std::shared_mutex>(e->rw);
+    e->writers_waiting.fetch_sub(1, std::memory_order_acq_rel);
+  }
+};
 
 template <class T>
 inline T* pin_host(vr_engine* e, size_t off) {

@@ -15,10 +15,13 @@ struct ProfRecord {
 };
 
 struct Profiler {
+  std::mutex mu;  // searches record from their lanes (any thread), writers from the master
   bool on = false;
   std::vector<ProfRecord> recs;
   std::vector<hipEvent_t> pool;
 };
+
+static thread_local int64_t tl_open = -1;  // the record this thread opened with prof_begin
 
 static Profiler* prof(vr_engine* e) { return static_cast<Profiler*>(e->profiler); }
 
@@ -29,7 +32,9 @@ bool prof_on(vr_engine* e) {
 
 void prof_begin(vr_engine* e, int cls, double work) {
   Profiler* p = prof(e);
+  tl_open = -1;
   if (!p || !p->on) return;
+  std::lock_guard<std::mutex> lock(p->mu);
   ProfRecord r{};
   for (hipEvent_t* ev : {&r.a, &r.b}) {
     if (!p->pool.empty()) {
@@ -43,12 +48,15 @@ void prof_begin(vr_engine* e, int cls, double work) {
   r.work = work;
   (void)hipEventRecord(r.a, e->stream);
   p->recs.push_back(r);
+  tl_open = static_cast<int64_t>(p->recs.size()) - 1;
 }
 
 void prof_end(vr_engine* e) {
   Profiler* p = prof(e);
-  if (!p || !p->on || p->recs.empty()) return;
-  (void)hipEventRecord(p->recs.back().b, e->stream);
+  if (!p || !p->on || tl_open < 0) return;
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (tl_open < static_cast<int64_t>(p->recs.size())) (void)hipEventRecord(p->recs[static_cast<size_t>(tl_open)].b, e->stream);
+  tl_open = -1;
 }
 
 void prof_release(vr_engine* e) {
@@ -81,9 +89,10 @@ extern "C" float vr_idf(int64_t n_points, int32_t df) {
 
 extern "C" int vr_profile(vr_engine* e, int enable) {
   VR_CHECK(e != nullptr, "null engine");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> lock(e->wmu);
   if (!e->profiler) e->profiler = new Profiler();
   Profiler* p = prof(e);
+  std::lock_guard<std::mutex> plock(p->mu);
   if (enable) {
     VR_HIP(hipStreamSynchronize(e->stream));
     for (ProfRecord& r : p->recs) {
@@ -99,7 +108,7 @@ extern "C" int vr_profile(vr_engine* e, int enable) {
 extern "C" int vr_profile_read(vr_engine* e, int kernel_class, double* total_ms, int64_t* launches,
                                double* total_work) {
   VR_CHECK(e != nullptr && total_ms && launches && total_work, "null argument");
-  std::lock_guard<std::mutex> lock(e->mu);
+  std::lock_guard<std::mutex> lock(e->wmu);
   *total_ms = 0.0;
   *launches = 0;
   *total_work = 0.0;
@@ -107,6 +116,7 @@ extern "C" int vr_profile_read(vr_engine* e, int kernel_class, double* total_ms,
   if (!p) return 0;
   VR_HIP(hipSetDevice(e->device));
   VR_HIP(hipStreamSynchronize(e->stream));
+  std::lock_guard<std::mutex> plock(p->mu);
   for (const ProfRecord& r : p->recs) {
     if (r.cls != kernel_class) continue;
     float ms = 0.0f;

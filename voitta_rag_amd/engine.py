@@ -263,6 +263,12 @@ class Engine:
             out[name] = int(v.value)
         return out
 
+    def generation(self) -> int:
+        """Bumped whenever row numbers change meaning (compaction, load): host tables keyed by row belong to one."""
+        v = C.c_int64()
+        check(self._lib.vr_stats(self._h, 5, C.byref(v)))
+        return int(v.value)
+
     def compact(self) -> np.ndarray:
         """Drop tombstoned rows; surviving rows are renumbered in order. Returns new_row_of_old
         (int64, -1 for dropped rows) so the caller can renumber whatever it keys by row."""

@@ -13,6 +13,7 @@ import json
 import logging
 import os
 import threading
+import time
 import uuid
 from dataclasses import dataclass
 
@@ -63,7 +64,16 @@ class _Collection:
     """Host half of one collection: payload rows and string dictionaries."""
 
     def __init__(self):
+        # lock        guards the host table; held for table reads / writes only, NEVER across an engine call —
+        #             so searches of several threads overlap in the engine (its search lanes)
+        # write_lock  one mutator at a time (store, delete, compact, save); searches do not take it
+        # version     bumped by every delete and compaction: a search maps its rows to payloads only if no such
+        #             mutation finished in between, else it searches again (its answer then belongs to the later state)
+        # generation  the engine generation (row numbering) the table corresponds to
         self.lock = threading.RLock()
+        self.write_lock = threading.RLock()
+        self.version = 0
+        self.generation = 0
         self.ids: list[str | None] = []        # row -> point id (None once deleted)
         self.payload: list[dict | None] = []   # row -> payload dict
         self.row_of: dict[str, int] = {}
@@ -133,6 +143,8 @@ class VectorStoreService:
             return _Collection()
 
         col = collection(self.collection_name, factory)
+        if fresh and hasattr(self._client, "generation"):
+            col.generation = self._client.generation()
         index_dir = get_settings().index_dir
         if fresh and index_dir and self.has_saved(index_dir) and self._client.count()[0] == 0:
             self._load_into(col, index_dir)
@@ -144,23 +156,29 @@ class VectorStoreService:
         purge: indexing.py:281-288,696-721,886-901) — the role of Qdrant's background optimiser.
         Returns the number of rows dropped; does nothing below ``min_dead_fraction`` tombstones."""
         col = self._col
-        with col.lock:
-            total = len(col.ids)
-            dead = sum(1 for p in col.payload if p is None)
+        with col.write_lock:
+            with col.lock:
+                total = len(col.ids)
+                dead = sum(1 for p in col.payload if p is None)
             if dead == 0 or dead < min_dead_fraction * total:
                 return 0
+            # the engine builds the compacted tables beside the live ones and swaps them in (searches keep running);
+            # between that swap and the renumbering below a search sees a generation mismatch and waits (search())
             remap = self.client.compact()
-            ids, payload = [], []
-            for pid, p in zip(col.ids, col.payload):
-                if p is not None:
-                    ids.append(pid)
-                    payload.append(p)
-            col.ids, col.payload = ids, payload
-            col.row_of = {pid: r for r, pid in enumerate(ids)}
-            col.rows_by_file = {}
-            for r, p in enumerate(payload):
-                col.rows_by_file.setdefault(p["file_path"], []).append(r)
-            assert int((remap >= 0).sum()) == len(ids)
+            with col.lock:
+                ids, payload = [], []
+                for pid, p in zip(col.ids, col.payload):
+                    if p is not None:
+                        ids.append(pid)
+                        payload.append(p)
+                col.ids, col.payload = ids, payload
+                col.row_of = {pid: r for r, pid in enumerate(ids)}
+                col.rows_by_file = {}
+                for r, p in enumerate(payload):
+                    col.rows_by_file.setdefault(p["file_path"], []).append(r)
+                assert int((remap >= 0).sum()) == len(ids)
+                col.generation = self.client.generation()
+                col.version += 1
             return dead
 
     # ---- persistence (SURVEY.md §8 row f2) ---------------------------------------------------------
@@ -220,7 +238,7 @@ class VectorStoreService:
             raise ValueError("no directory given and VOITTA_INDEX_DIR is not set")
         os.makedirs(directory, exist_ok=True)
         col = self._col
-        with col.lock:
+        with col.write_lock, col.lock:
             try:
                 previous = self._read_meta(directory)
             except (OSError, ValueError):
@@ -317,6 +335,8 @@ class VectorStoreService:
             col.ids, col.payload, col.row_of, col.rows_by_file = ids, payloads, row_of, rows_by_file
             col.folder_ids = {k: int(v) for k, v in meta["folder_ids"].items()}
             col.index_folder_ids = {k: int(v) for k, v in meta["index_folder_ids"].items()}
+            col.generation = self._client.generation() if hasattr(self._client, "generation") else 0
+            col.version += 1
         logger.info("Loaded %d rows of collection '%s' from %s", len(col.ids), self.collection_name, directory)
         return len(col.ids)
 
@@ -373,22 +393,30 @@ class VectorStoreService:
             score=score,
         )
 
-    def _delete_rows(self, rows: list[int]) -> int:
+    def _delete_where(self, select) -> int:
+        """Delete the live rows ``select(col)`` returns (evaluated under the table lock). Engine first — from then on
+        no search returns the rows — then the host table; the version bump makes a search that straddled the two
+        steps look again."""
         col = self._col
-        rows = [r for r in rows if col.payload[r] is not None]
-        if rows:
+        with col.write_lock:
+            with col.lock:
+                rows = [r for r in select(col) if col.payload[r] is not None]
+            if not rows:
+                return 0
             self.client.delete_rows(np.asarray(rows, np.int64))
-            for r in rows:
-                p = col.payload[r]
-                lst = col.rows_by_file.get(p["file_path"])
-                if lst is not None:
-                    lst.remove(r)
-                    if not lst:
-                        del col.rows_by_file[p["file_path"]]
-                col.row_of.pop(col.ids[r], None)
-                col.payload[r] = None
-                col.ids[r] = None
-        return len(rows)
+            with col.lock:
+                for r in rows:
+                    p = col.payload[r]
+                    lst = col.rows_by_file.get(p["file_path"])
+                    if lst is not None:
+                        lst.remove(r)
+                        if not lst:
+                            del col.rows_by_file[p["file_path"]]
+                    col.row_of.pop(col.ids[r], None)
+                    col.payload[r] = None
+                    col.ids[r] = None
+                col.version += 1
+            return len(rows)
 
     # ---- store ------------------------------------------------------------------------------------
     def store_chunks(self, chunks: list[tuple[str, list[float], ChunkMetadata]],
@@ -401,30 +429,56 @@ class VectorStoreService:
         col = self._col
         n = len(chunks)
         dense = np.asarray([c[1] for c in chunks], dtype=np.float32).reshape(n, self.dimension)
-        with col.lock:
-            folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
-            ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
-            created = np.array([VR_TS_ABSENT if c[2].source_created_at is None else int(c[2].source_created_at)
-                                for c in chunks], np.int64)
-            modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
-                                 for c in chunks], np.int64)
-            sparse = None
-            if sparse_vectors:
-                # a chunk beyond len(sparse_vectors) is stored dense-only (:291,299-300): empty row here
-                sparse = [sparse_vectors[i] if i < len(sparse_vectors) else ([], []) for i in range(n)]
-            first = self.client.upsert(dense, sparse=sparse, folder_ids=folder, index_folder_ids=ifolder,
-                                       created=created, modified=modified)
-            assert first == len(col.payload), "host table and engine rows diverged"
-            ids = []
-            for i, (text, _emb, metadata) in enumerate(chunks):
-                point_id = str(uuid.uuid4())  # :256
-                ids.append(point_id)
-                col.ids.append(point_id)
-                col.payload.append(self._payload_of(text, metadata))
-                col.row_of[point_id] = first + i
-                col.rows_by_file.setdefault(metadata.file_path, []).append(first + i)
+        ids = [str(uuid.uuid4()) for _ in chunks]  # :256
+        payloads = [self._payload_of(text, metadata) for text, _emb, metadata in chunks]
+        sparse = None
+        if sparse_vectors:
+            # a chunk beyond len(sparse_vectors) is stored dense-only (:291,299-300): empty row here
+            sparse = [sparse_vectors[i] if i < len(sparse_vectors) else ([], []) for i in range(n)]
+        created = np.array([VR_TS_ABSENT if c[2].source_created_at is None else int(c[2].source_created_at)
+                            for c in chunks], np.int64)
+        modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
+                             for c in chunks], np.int64)
+        with col.write_lock:
+            first = self._append_host_rows(col, ids, payloads)
+            with col.lock:
+                folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
+                ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
+            try:  # the host rows exist before the engine can return their row numbers; the engine call holds no table lock
+                got = self.client.upsert(dense, sparse=sparse, folder_ids=folder, index_folder_ids=ifolder,
+                                         created=created, modified=modified)
+                assert got == first, "host table and engine rows diverged"
+            except BaseException:
+                self._drop_host_rows(col, first, ids, payloads)
+                raise
         logger.info(f"Stored {n} chunks in the native engine")
         return ids
+
+    @staticmethod
+    def _append_host_rows(col: _Collection, ids: list[str], payloads: list[dict]) -> int:
+        with col.lock:
+            first = len(col.payload)
+            col.ids.extend(ids)
+            col.payload.extend(payloads)
+            col.row_of.update(zip(ids, range(first, first + len(ids))))
+            for i, payload in enumerate(payloads):
+                col.rows_by_file.setdefault(payload["file_path"], []).append(first + i)
+        return first
+
+    @staticmethod
+    def _drop_host_rows(col: _Collection, first: int, ids: list[str], payloads: list[dict]) -> None:
+        """Undo _append_host_rows after a failed engine call (nothing else was appended: the write lock is held)."""
+        with col.lock:
+            del col.ids[first:]
+            del col.payload[first:]
+            for pid in ids:
+                col.row_of.pop(pid, None)
+            for i, payload in enumerate(payloads):
+                lst = col.rows_by_file.get(payload["file_path"])
+                if lst and first + i in lst:
+                    lst.remove(first + i)
+                    if not lst:
+                        del col.rows_by_file[payload["file_path"]]
 
     @classmethod
     def prepare_rows(cls, texts: list[str], metadatas: list[ChunkMetadata]) -> tuple[list[str], list[dict]]:
@@ -450,44 +504,39 @@ class VectorStoreService:
         ids, payloads = rows if rows is not None else self.prepare_rows(texts, metadatas)
         assert len(ids) == n and len(payloads) == n
         col = self._col
-        with col.lock:
-            folder = np.array([col.folder_id(m.folder_path, True) for m in metadatas], np.int32)
-            ifolder = np.array([col.index_folder_id(m.index_folder, True) for m in metadatas], np.int32)
-            created = np.array([VR_TS_ABSENT if m.source_created_at is None else int(m.source_created_at)
-                                for m in metadatas], np.int64)
-            modified = np.array([VR_TS_ABSENT if m.source_modified_at is None else int(m.source_modified_at)
-                                 for m in metadatas], np.int64)
-            first = self.client.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
-                                            created=created, modified=modified)
-            assert first == len(col.payload), "host table and engine rows diverged"
-            col.ids.extend(ids)
-            col.payload.extend(payloads)
-            col.row_of.update(zip(ids, range(first, first + n)))
-            for i, metadata in enumerate(metadatas):
-                col.rows_by_file.setdefault(metadata.file_path, []).append(first + i)
+        created = np.array([VR_TS_ABSENT if m.source_created_at is None else int(m.source_created_at)
+                            for m in metadatas], np.int64)
+        modified = np.array([VR_TS_ABSENT if m.source_modified_at is None else int(m.source_modified_at)
+                             for m in metadatas], np.int64)
+        with col.write_lock:
+            first = self._append_host_rows(col, ids, payloads)
+            with col.lock:
+                folder = np.array([col.folder_id(m.folder_path, True) for m in metadatas], np.int32)
+                ifolder = np.array([col.index_folder_id(m.index_folder, True) for m in metadatas], np.int32)
+            try:
+                got = self.client.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
+                                              created=created, modified=modified)
+                assert got == first, "host table and engine rows diverged"
+            except BaseException:
+                self._drop_host_rows(col, first, ids, payloads)
+                raise
         return ids
 
     # ---- deletes / ACL ----------------------------------------------------------------------------
     def delete_by_file(self, file_path: str) -> int:
-        col = self._col
-        with col.lock:
-            count = self._delete_rows(list(col.rows_by_file.get(file_path, [])))
+        count = self._delete_where(lambda col: list(col.rows_by_file.get(file_path, [])))
         if count > 0:
             logger.info(f"Deleted {count} chunks for file: {file_path}")
         return count
 
     def delete_by_folder(self, folder_path: str) -> int:
-        col = self._col
-        with col.lock:
-            count = self._delete_rows([r for r in col.live_rows() if col.payload[r]["folder_path"] == folder_path])
+        count = self._delete_where(lambda col: [r for r in col.live_rows() if col.payload[r]["folder_path"] == folder_path])
         if count > 0:
             logger.info(f"Deleted {count} chunks for folder: {folder_path}")
         return count
 
     def delete_by_index_folder(self, index_folder: str) -> int:
-        col = self._col
-        with col.lock:
-            count = self._delete_rows([r for r in col.live_rows() if col.payload[r].get("index_folder") == index_folder])
+        count = self._delete_where(lambda col: [r for r in col.live_rows() if col.payload[r].get("index_folder") == index_folder])
         if count > 0:
             logger.info(f"Deleted {count} chunks for index_folder: {index_folder}")
         return count
@@ -529,17 +578,32 @@ class VectorStoreService:
             return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
         q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
-        with col.lock:
-            search_filter = self._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
-                                               date_start=date_start, date_end=date_end, date_field=date_field)
-            if sparse_query and self._has_sparse:
-                indices, values = sparse_query
-                if indices:
-                    rows, scores, _ = self.client.search_hybrid(q, indices, values, limit, sparse_weight,
-                                                                flt=search_filter)
-                    return [self._chunk_from(col.ids[r], col.payload[r], float(s)) for r, s in zip(rows, scores)]
-            rows, scores = self.client.search_dense(q[None, :], limit, search_filter)[0]
-            return [self._chunk_from(col.ids[r], col.payload[r], _json_float(s)) for r, s in zip(rows, scores)]
+        hybrid = bool(sparse_query and self._has_sparse and sparse_query[0])
+        for attempt in range(64):
+            with col.lock:
+                search_filter = self._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
+                                                   date_start=date_start, date_end=date_end, date_field=date_field)
+                version, generation = col.version, col.generation
+            # the engine call holds no Python lock: searches of several threads run side by side on the engine's lanes
+            if hasattr(self.client, "generation") and self.client.generation() != generation:
+                time.sleep(0.0005)  # a compaction has swapped the engine's tables, the host table follows in a moment
+                continue
+            if hybrid:
+                rows, scores, _ = self.client.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight,
+                                                            flt=search_filter)
+                scores = [float(s) for s in scores]
+            else:
+                rows, scores = self.client.search_dense(q[None, :], limit, search_filter)[0]
+                scores = [_json_float(s) for s in scores]
+            with col.lock:
+                # rows -> payloads, unless a delete or a compaction finished meanwhile (the rows might be gone or
+                # renumbered): then look again — the new answer belongs to the state after that mutation
+                unchanged = col.version == version and (not hasattr(self.client, "generation")
+                                                        or self.client.generation() == col.generation == generation)
+                if unchanged or attempt == 63:
+                    return [self._chunk_from(col.ids[r], col.payload[r], s) for r, s in zip(rows, scores)
+                            if r < len(col.payload) and col.payload[r] is not None]
+        return []
 
     # ---- read helpers (payload only) ---------------------------------------------------------------
     def find_by_source_url(self, source_url: str) -> list[StoredChunk]:
