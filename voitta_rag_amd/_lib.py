@@ -144,7 +144,12 @@ def load_library():
             "(or `make -C voitta_rag_amd/csrc`). There is no CPU fallback."
         )
     lib = C.CDLL(path)
+    # VOITTA_ENGINE_HOST_ONLY=1: a library that carries only the host-only entry points (the sanitizer build of the
+    # tokenizers, the chunker and the fusion — `make asan`); everything that needs the GPU is simply absent from it
+    host_only = os.environ.get("VOITTA_ENGINE_HOST_ONLY") == "1"
     for name, (restype, argtypes) in SIGNATURES.items():
+        if host_only and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = restype
         fn.argtypes = argtypes
