@@ -385,3 +385,48 @@ def test_save_is_atomic_and_a_damaged_snapshot_is_refused_cleanly(native, tmp_pa
         shutil.copy(payload + ".keep", payload)
         shutil.copy(index + ".keep", index)
         assert len(vs3.search(q, limit=5)) == 5  # repaired: the same object recovers without a restart
+
+
+def test_write_behind_stores_exactly_what_the_three_literal_calls_store(native, monkeypatch):
+    """voitta_rag_amd/deferred.py: the per-file sequence of indexing.py:527-560 with embeddings nobody looks at (stored by
+    fused vr_index_batch calls from the flusher thread) leaves the same bits in the engine — dense rows, sparse rows,
+    filter columns — as the same sequence with VOITTA_DEFERRED_INDEXING=0 (encode -> Python floats -> upsert)."""
+    from voitta_rag_amd import deferred, embedding, sparse_embedding, store_registry, vector_store
+    from voitta_rag_amd.vector_store import ChunkMetadata
+
+    rng = np.random.default_rng(5)
+    files = [(f"d{f % 3}/f{f}.md", _texts(rng, int(rng.integers(1, 40)))) for f in range(25)]
+    queries = ["vector database retrieval", "running happily", "kernel memory"]
+
+    def run(defer):
+        native(f"wb-model-{int(defer)}")
+        monkeypatch.setenv("VOITTA_DEFERRED_INDEXING", "1" if defer else "0")
+        emb, sp, vs = embedding.get_embedding_service(), sparse_embedding.get_sparse_embedding_service(), vector_store.get_vector_store()
+        for fp, texts in files:
+            embeddings = emb.embed_texts(texts)
+            sparse_vectors = sp.embed_texts(texts)
+            assert isinstance(embeddings, deferred.DeferredEmbeddings) == defer and isinstance(embeddings, list)
+            metas = [ChunkMetadata(file_path=fp, folder_path=fp.split("/")[0], index_folder=fp.split("/")[0], file_name=fp.split("/")[1],
+                                   chunk_index=i, total_chunks=len(texts), start_char=0, end_char=1, indexed_at="t",
+                                   source_modified_at=1_700_000_000 + i) for i in range(len(texts))]
+            vs.store_chunks([(t, e, m) for t, e, m in zip(texts, embeddings, metas)], sparse_vectors=sparse_vectors)
+            assert not defer or not embeddings.materialized  # nobody looked: the fused path took them
+        n = sum(len(t) for _, t in files)
+        assert vs.get_collection_info()["points_count"] == n
+        engine = vs.client
+        dense = engine.get_dense(np.arange(n))
+        answers = []
+        for q in queries:
+            got = vs.search(emb.embed_query(q), limit=10, sparse_query=sp.embed_query(q), sparse_weight=0.3,
+                            folder_filter="d1" if q.startswith("k") else None, date_start=1_700_000_002)
+            answers.append([(c.metadata.file_path, c.metadata.chunk_index, c.score) for c in got])
+            sq = sp.embed_query(q)
+            rows, scores = engine.search_sparse(np.array(sq[0], np.int32), np.array(sq[1], np.float32), 50)
+            answers.append((rows.tolist(), scores.tolist()))
+        stats = engine.stats() if hasattr(engine, "stats") else {}
+        return dense, answers, stats
+
+    d1, a1, _ = run(True)
+    d0, a0, _ = run(False)
+    assert np.array_equal(d1, d0) and a1 == a0
+    store_registry.reset()

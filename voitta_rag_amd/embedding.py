@@ -15,6 +15,7 @@ import os
 
 import numpy as np
 
+from . import deferred as _deferred
 from . import encoder as _enc
 from .config import get_settings
 from .store_registry import get_engine
@@ -196,6 +197,10 @@ class EmbeddingService:
             return []
         if "e5" in self.model_name.lower():  # embedding.py:65-66
             texts = [f"passage: {text}" for text in texts]
+        if _deferred.enabled():
+            # tokenised now, encoded when somebody looks at a number — or, when the list goes to store_chunks
+            # untouched, together with thousands of other chunks inside the engine (voitta_rag_amd/deferred.py)
+            return _deferred.DeferredEmbeddings(self.model, *self.model.tokenize(list(texts)))
         embeddings = self.model.encode(texts, batch_size=batch_size, convert_to_numpy=True,
                                        show_progress_bar=len(texts) > 100)
         return embeddings.tolist()

@@ -10,6 +10,7 @@ from typing import Optional
 import numpy as np
 
 from . import bm25 as _bm25
+from . import deferred as _deferred
 from .store_registry import get_engine
 
 SPARSE_VECTOR_NAME = "bm25"  # the named sparse vector of the collection (sparse_embedding.py:9)
@@ -36,6 +37,8 @@ class SparseEmbeddingService:
         if len(texts) == 0:
             return []
         offsets, stems = _bm25.hashed_stems(texts)
+        if _deferred.enabled():  # the tf weights are computed when looked at, or inside the fused store
+            return _deferred.DeferredSparse(self.model, offsets, stems)
         return [(idx.tolist(), val.tolist()) for idx, val in self.model.bm25_tf(offsets, stems)]
 
     def embed_query(self, query: str) -> tuple[list[int], list[float]]:

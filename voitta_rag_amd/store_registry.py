@@ -24,10 +24,19 @@ def get_engine():
         return _engine
 
 
+def _stop_collections() -> None:
+    """(under _lock) end the write-behind threads of the registered collections before their engine goes away"""
+    for col in _collections.values():
+        stop = getattr(col, "stop", None)
+        if stop is not None:
+            stop()
+
+
 def set_engine(engine) -> None:
     """Tests and multi-GPU launchers install their own engine."""
     global _engine
     with _lock:
+        _stop_collections()
         _engine = engine
         _collections.clear()
 
@@ -42,6 +51,7 @@ def collection(name: str, factory):
 def reset() -> None:
     global _engine
     with _lock:
+        _stop_collections()
         if _engine is not None:
             _engine.close()
         _engine = None
@@ -55,6 +65,9 @@ def replace(engine, collections: dict) -> None:
     with _lock:
         old = _engine
         _engine = engine
+        for col in _collections.values():
+            if all(col is not kept for kept in collections.values()) and hasattr(col, "stop"):
+                col.stop()
         _collections.clear()
         _collections.update(collections)
     if old is not None and old is not engine:
@@ -64,4 +77,6 @@ def replace(engine, collections: dict) -> None:
 def forget(name: str) -> None:
     """Drop a host table that was registered only to be saved under its own name."""
     with _lock:
-        _collections.pop(name, None)
+        col = _collections.pop(name, None)
+        if col is not None and hasattr(col, "stop"):
+            col.stop()

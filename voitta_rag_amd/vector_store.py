@@ -9,6 +9,7 @@ get_* helpers swallow exceptions and return 0 / {} / [] / None (vector_store.py:
 894,975,1014)."""
 from __future__ import annotations
 
+import contextlib
 import json
 import logging
 import os
@@ -19,6 +20,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
+from . import deferred as _deferred
 from .config import get_settings
 from .engine import VR_TS_ABSENT, SearchFilter
 from .sparse_embedding import SPARSE_VECTOR_NAME  # noqa: F401  (re-exported like the reference)
@@ -80,6 +82,27 @@ class _Collection:
         self.rows_by_file: dict[str, list[int]] = {}
         self.folder_ids: dict[str, int] = {}
         self.index_folder_ids: dict[str, int] = {}
+        # write-behind (voitta_rag_amd/deferred.py): stores whose rows are in the host table above but whose
+        # vectors the engine has not computed yet, oldest first. Guarded by pending_cv; entries are appended
+        # under write_lock (so queue order = row order) and consumed by ONE flusher thread.
+        self.pending_cv = threading.Condition()
+        self.pending: list[dict] = []
+        self.pending_rows = 0
+        self.flushing = False
+        self.drain_waiters = 0
+        self.flusher: threading.Thread | None = None
+        self.stopped = False
+        self.deferred_error: BaseException | None = None
+
+    def stop(self) -> None:
+        """End the flusher thread; queued stores are dropped (the engine they were meant for is going away)."""
+        with self.pending_cv:
+            self.stopped = True
+            self.pending, self.pending_rows = [], 0
+            self.pending_cv.notify_all()
+        t = self.flusher
+        if t is not None and t is not threading.current_thread():
+            t.join(timeout=60)
 
     def folder_id(self, name: str, create: bool) -> int:
         if name not in self.folder_ids:
@@ -118,6 +141,14 @@ class VectorStoreService:
     # ---- the "client": engine + host table ------------------------------------------------------
     @property
     def client(self):
+        """The engine behind the collection, for callers outside this class: rows whose store was deferred
+        (voitta_rag_amd/deferred.py) are in it when this returns."""
+        engine = self._engine
+        self._drain(collection(self.collection_name, _Collection))
+        return engine
+
+    @property
+    def _engine(self):
         if self._client is None:
             logger.info("Binding collection '%s' to the native engine", self.collection_name)
             self._client = get_engine()
@@ -157,6 +188,7 @@ class VectorStoreService:
         Returns the number of rows dropped; does nothing below ``min_dead_fraction`` tombstones."""
         col = self._col
         with col.write_lock:
+            self._drain(col)
             with col.lock:
                 total = len(col.ids)
                 dead = sum(1 for p in col.payload if p is None)
@@ -164,7 +196,7 @@ class VectorStoreService:
                 return 0
             # the engine builds the compacted tables beside the live ones and swaps them in (searches keep running);
             # between that swap and the renumbering below a search sees a generation mismatch and waits (search())
-            remap = self.client.compact()
+            remap = self._engine.compact()
             with col.lock:
                 ids, payload = [], []
                 for pid, p in zip(col.ids, col.payload):
@@ -177,7 +209,7 @@ class VectorStoreService:
                 for r, p in enumerate(payload):
                     col.rows_by_file.setdefault(p["file_path"], []).append(r)
                 assert int((remap >= 0).sum()) == len(ids)
-                col.generation = self.client.generation()
+                col.generation = self._engine.generation()
                 col.version += 1
             return dead
 
@@ -238,14 +270,17 @@ class VectorStoreService:
             raise ValueError("no directory given and VOITTA_INDEX_DIR is not set")
         os.makedirs(directory, exist_ok=True)
         col = self._col
-        with col.write_lock, col.lock:
+        with contextlib.ExitStack() as held:
+            held.enter_context(col.write_lock)
+            self._drain(col)  # (the flusher needs the table lock only to take rows back after a failure)
+            held.enter_context(col.lock)
             try:
                 previous = self._read_meta(directory)
             except (OSError, ValueError):
                 previous = None  # an unreadable pointer names nothing worth keeping
             generation = int(previous.get("generation", 0)) + 1 if previous else 1
             index_path, payload_path, meta_path = self._paths(directory, generation)
-            self.client.save(index_path)  # tmp + fsync + rename inside vr_save
+            self._engine.save(index_path)  # tmp + fsync + rename inside vr_save
             index_bytes, index_digest = self._index_digest(index_path)
 
             def write_payload(f):
@@ -342,7 +377,7 @@ class VectorStoreService:
 
     @property
     def _col(self) -> _Collection:
-        self.client  # noqa: B018  (lazy bind)
+        self._engine  # noqa: B018  (lazy bind)
         return collection(self.collection_name, _Collection)
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -399,11 +434,12 @@ class VectorStoreService:
         steps look again."""
         col = self._col
         with col.write_lock:
+            self._drain(col)  # the rows to delete may still be on their way into the engine
             with col.lock:
                 rows = [r for r in select(col) if col.payload[r] is not None]
             if not rows:
                 return 0
-            self.client.delete_rows(np.asarray(rows, np.int64))
+            self._engine.delete_rows(np.asarray(rows, np.int64))
             with col.lock:
                 for r in rows:
                     p = col.payload[r]
@@ -428,6 +464,10 @@ class VectorStoreService:
             return []
         col = self._col
         n = len(chunks)
+        if _deferred.enabled():
+            taken = _deferred.take_deferred(chunks, sparse_vectors)
+            if taken is not None and chunks[0][1].batch.encoder.engine is self._engine and chunks[0][1].batch.dim == self.dimension:
+                return self._store_deferred(col, chunks, *taken)
         dense = np.asarray([c[1] for c in chunks], dtype=np.float32).reshape(n, self.dimension)
         ids = [str(uuid.uuid4()) for _ in chunks]  # :256
         payloads = [self._payload_of(text, metadata) for text, _emb, metadata in chunks]
@@ -440,12 +480,13 @@ class VectorStoreService:
         modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
                              for c in chunks], np.int64)
         with col.write_lock:
+            self._drain(col)  # rows stored before these come before them in the engine too
             first = self._append_host_rows(col, ids, payloads)
             with col.lock:
                 folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
                 ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
             try:  # the host rows exist before the engine can return their row numbers; the engine call holds no table lock
-                got = self.client.upsert(dense, sparse=sparse, folder_ids=folder, index_folder_ids=ifolder,
+                got = self._engine.upsert(dense, sparse=sparse, folder_ids=folder, index_folder_ids=ifolder,
                                          created=created, modified=modified)
                 assert got == first, "host table and engine rows diverged"
             except BaseException:
@@ -453,6 +494,122 @@ class VectorStoreService:
                 raise
         logger.info(f"Stored {n} chunks in the native engine")
         return ids
+
+    # ---- write-behind for embeddings that were never looked at (voitta_rag_amd/deferred.py) -----------
+    _FLUSH_ROWS = int(os.environ.get("VOITTA_DEFERRED_ROWS", "4096"))        # a batch this large goes at once
+    _FLUSH_LINGER_S = float(os.environ.get("VOITTA_DEFERRED_LINGER_MS", "20")) * 1e-3  # a smaller one waits this long for company
+    _MAX_PENDING_ROWS = 16 * _FLUSH_ROWS                                      # the caller waits beyond this
+
+    def _store_deferred(self, col: _Collection, chunks, wp_ids, wp_off, bm_ids, bm_off) -> list[str]:
+        """store_chunks for chunks whose embeddings are still token ids: the host table gets its rows now, the
+        engine gets them from the flusher thread (one vr_index_batch per few thousand chunks)."""
+        n = len(chunks)
+        ids = [str(uuid.uuid4()) for _ in chunks]  # vector_store.py:256
+        payloads = [self._payload_of(text, metadata) for text, _emb, metadata in chunks]
+        created = np.array([VR_TS_ABSENT if c[2].source_created_at is None else int(c[2].source_created_at)
+                            for c in chunks], np.int64)
+        modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
+                             for c in chunks], np.int64)
+        if bm_off is None:  # dense-only store: rows without a sparse vector = empty rows (as in store_chunks above)
+            bm_ids, bm_off = np.zeros(0, np.int32), np.zeros(n + 1, np.int64)
+        with col.pending_cv:
+            while col.pending_rows > self._MAX_PENDING_ROWS and not col.stopped and col.deferred_error is None:
+                col.pending_cv.wait(0.05)
+        with col.write_lock:
+            self._raise_deferred_error(col)
+            first = self._append_host_rows(col, ids, payloads)
+            with col.lock:
+                folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
+                ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
+            entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(),
+                         wp_ids=np.asarray(wp_ids, np.int32), wp_off=np.asarray(wp_off, np.int64),
+                         bm_ids=np.asarray(bm_ids, np.int32), bm_off=np.asarray(bm_off, np.int64),
+                         folder=folder, ifolder=ifolder, created=created, modified=modified)
+            with col.pending_cv:
+                if col.stopped:
+                    self._drop_host_rows(col, first, ids, payloads)
+                    raise RuntimeError("the collection was closed")
+                col.pending.append(entry)
+                col.pending_rows += n
+                if col.flusher is None or not col.flusher.is_alive():
+                    col.flusher = threading.Thread(target=self._flush_loop, args=(col,), name="voitta-store-flusher", daemon=True)
+                    col.flusher.start()
+                if col.pending_rows >= self._FLUSH_ROWS:
+                    col.pending_cv.notify_all()
+        return ids
+
+    @classmethod
+    def _flush_loop(cls, col: _Collection) -> None:
+        while True:
+            with col.pending_cv:
+                while not col.stopped:
+                    if col.pending and (col.pending_rows >= cls._FLUSH_ROWS or col.drain_waiters
+                                        or time.monotonic() - col.pending[0]["t"] >= cls._FLUSH_LINGER_S):
+                        break
+                    col.pending_cv.wait(cls._FLUSH_LINGER_S if col.pending else None)
+                if col.stopped:
+                    return
+                batch, col.pending, col.pending_rows = col.pending, [], 0
+                col.flushing = True
+            try:
+                cls._flush(col, batch)
+            except BaseException as e:  # noqa: BLE001  (reported to the next caller, see _raise_deferred_error)
+                logger.error("deferred store of %d chunks failed: %r", sum(b["n"] for b in batch), e)
+                with col.pending_cv:
+                    later, col.pending, col.pending_rows = col.pending, [], 0
+                    col.deferred_error = e
+                for b in reversed(batch + later):  # none of these rows reached the engine: take them back, newest first
+                    cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
+            finally:
+                with col.pending_cv:
+                    col.flushing = False
+                    col.pending_cv.notify_all()
+
+    @staticmethod
+    def _flush(col: _Collection, batch: list[dict]) -> None:
+        engine = batch[0]["engine"]
+        cat = lambda key: batch[0][key] if len(batch) == 1 else np.concatenate([b[key] for b in batch])  # noqa: E731
+
+        def offsets(key):
+            if len(batch) == 1:
+                return batch[0][key]
+            out, base = [batch[0][key]], int(batch[0][key][-1])
+            for b in batch[1:]:
+                out.append(b[key][1:] + base)
+                base += int(b[key][-1])
+            return np.concatenate(out)
+
+        got = engine.index_batch(cat("wp_ids"), offsets("wp_off").astype(np.int32), cat("bm_ids"), offsets("bm_off"),
+                                 folder_ids=cat("folder"), index_folder_ids=cat("ifolder"),
+                                 created=cat("created"), modified=cat("modified"))
+        if got != batch[0]["first"]:
+            raise RuntimeError(f"host table and engine rows diverged ({batch[0]['first']} vs {got})")
+
+    @staticmethod
+    def _raise_deferred_error(col: _Collection) -> None:
+        with col.pending_cv:
+            err, col.deferred_error = col.deferred_error, None
+        if err is not None:
+            raise RuntimeError("an earlier store_chunks could not be completed by the engine; its rows were dropped") from err
+
+    def _drain(self, col: _Collection) -> None:
+        """Returns when every store_chunks that returned before this call is in the engine (read-your-writes)."""
+        if col.flusher is None:
+            return
+        with col.pending_cv:
+            if col.pending or col.flushing:
+                col.drain_waiters += 1
+                col.pending_cv.notify_all()
+                try:
+                    while (col.pending or col.flushing) and not col.stopped:
+                        col.pending_cv.wait(0.5)
+                finally:
+                    col.drain_waiters -= 1
+        self._raise_deferred_error(col)
+
+    def flush(self) -> None:
+        """Wait until everything stored so far is searchable (it becomes so by itself within a few ms)."""
+        self._drain(self._col)
 
     @staticmethod
     def _append_host_rows(col: _Collection, ids: list[str], payloads: list[dict]) -> int:
@@ -509,12 +666,13 @@ class VectorStoreService:
         modified = np.array([VR_TS_ABSENT if m.source_modified_at is None else int(m.source_modified_at)
                              for m in metadatas], np.int64)
         with col.write_lock:
+            self._drain(col)
             first = self._append_host_rows(col, ids, payloads)
             with col.lock:
                 folder = np.array([col.folder_id(m.folder_path, True) for m in metadatas], np.int32)
                 ifolder = np.array([col.index_folder_id(m.index_folder, True) for m in metadatas], np.int32)
             try:
-                got = self.client.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
+                got = self._engine.index_batch(wp_ids, wp_off, bm_ids, bm_off, folder_ids=folder, index_folder_ids=ifolder,
                                               created=created, modified=modified)
                 assert got == first, "host table and engine rows diverged"
             except BaseException:
@@ -577,6 +735,7 @@ class VectorStoreService:
         if limit <= 0:
             return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
+        self._drain(col)
         q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
         hybrid = bool(sparse_query and self._has_sparse and sparse_query[0])
         for attempt in range(64):
@@ -585,21 +744,21 @@ class VectorStoreService:
                                                    date_start=date_start, date_end=date_end, date_field=date_field)
                 version, generation = col.version, col.generation
             # the engine call holds no Python lock: searches of several threads run side by side on the engine's lanes
-            if hasattr(self.client, "generation") and self.client.generation() != generation:
+            if hasattr(self._engine, "generation") and self._engine.generation() != generation:
                 time.sleep(0.0005)  # a compaction has swapped the engine's tables, the host table follows in a moment
                 continue
             if hybrid:
-                rows, scores, _ = self.client.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight,
+                rows, scores, _ = self._engine.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight,
                                                             flt=search_filter)
                 scores = [float(s) for s in scores]
             else:
-                rows, scores = self.client.search_dense(q[None, :], limit, search_filter)[0]
+                rows, scores = self._engine.search_dense(q[None, :], limit, search_filter)[0]
                 scores = [_json_float(s) for s in scores]
             with col.lock:
                 # rows -> payloads, unless a delete or a compaction finished meanwhile (the rows might be gone or
                 # renumbered): then look again — the new answer belongs to the state after that mutation
-                unchanged = col.version == version and (not hasattr(self.client, "generation")
-                                                        or self.client.generation() == col.generation == generation)
+                unchanged = col.version == version and (not hasattr(self._engine, "generation")
+                                                        or self._engine.generation() == col.generation == generation)
                 if unchanged or attempt == 63:
                     return [self._chunk_from(col.ids[r], col.payload[r], s) for r, s in zip(rows, scores)
                             if r < len(col.payload) and col.payload[r] is not None]
