@@ -72,18 +72,26 @@ tok = emb.model.tokenize([c.text for c in get_chunking_service().chunk_text(file
 print(f"{n_files} files, {chars / 1e6:.1f} M chars -> {n} chunks ({chars / n:.0f} chars, ~{tok[1][-1] / (len(tok[1]) - 1):.0f} tokens each), {layers} layers")
 print(f"(b) BulkIndexer            : {t1 - t0:6.2f} s = {n / (t1 - t0):8.0f} chunks/s from raw text")
 
-# (a) the reference's per-file sequence on the native services
-emb, sp, vs = fresh()
-chunker = get_chunking_service()
+# (a) the reference's per-file sequence on the native services: write-behind (default), then literal
+def per_file(sub):
+    emb, sp, vs = fresh()
+    chunker = get_chunking_service()
+    t0 = time.perf_counter(); m = 0
+    for f in sub:
+        chunks = chunker.chunk_text(f.content)
+        texts = [c.text for c in chunks]
+        e, s = emb.embed_texts(texts), sp.embed_texts(texts)
+        vs.store_chunks([(c.text, v, ChunkMetadata(f.file_path, f.folder_path, f.index_folder, f.file_name, c.index, len(chunks),
+                                                   c.start_char, c.end_char, "t", source_modified_at=f.source_modified_at))
+                         for c, v in zip(chunks, e)], sparse_vectors=s)
+        m += len(chunks)
+    vs.client.sync(); t1 = time.perf_counter()  # (.client waits for the flusher)
+    return m, t1 - t0
+
+per_file(files[:40])
+m, dt = per_file(files)
+print(f"(a) per-file, write-behind  : {dt:6.2f} s = {m / dt:8.0f} chunks/s ({len(files)} files)")
+os.environ["VOITTA_DEFERRED_INDEXING"] = "0"
 sub = files[: max(40, n_files // 4)]
-t0 = time.perf_counter(); m = 0
-for f in sub:
-    chunks = chunker.chunk_text(f.content)
-    texts = [c.text for c in chunks]
-    e, s = emb.embed_texts(texts), sp.embed_texts(texts)
-    vs.store_chunks([(c.text, v, ChunkMetadata(f.file_path, f.folder_path, f.index_folder, f.file_name, c.index, len(chunks),
-                                               c.start_char, c.end_char, "t", source_modified_at=f.source_modified_at))
-                     for c, v in zip(chunks, e)], sparse_vectors=s)
-    m += len(chunks)
-vs.client.sync(); t1 = time.perf_counter()
-print(f"(a) per-file, list-of-floats: {t1 - t0:6.2f} s = {m / (t1 - t0):8.0f} chunks/s ({len(sub)} files)")
+m, dt = per_file(sub)
+print(f"(a0) per-file, list-of-floats: {dt:6.2f} s = {m / dt:8.0f} chunks/s ({len(sub)} files)")

@@ -149,12 +149,21 @@ def test_subset_reordered_and_dense_only_stores(store):
     want = ocore.cosine_preprocess(toy_embed(r[0], r[1]))
     pick = [4, 0, 3]
     vs.store_chunks([(f"s:{i}", emb[i], metas[i]) for i in pick])  # no sparse vectors: dense-only rows
+    e0, s0, m0, r0 = store.file_of("s0.md", 2)  # queued right behind it, WITH sparse vectors: a fused call of its own
+    vs.store_chunks([(f"s0:{i}", e, m) for i, (e, m) in enumerate(zip(e0, m0))], sparse_vectors=s0)
     vs.flush()
-    assert np.array_equal(engine.x, want[pick]) and all(len(row[0]) == 0 for row in engine.sp)
+    assert engine.batches == [3, 2] and engine.sp[3] is not None and engine.sp[2] is None
+    vs.delete_by_file("s0.md")
+    engine.x, engine.sp, engine.live = engine.x[:3], engine.sp[:3], engine.live[:3]  # (back to three rows for the checks below)
+    for a in ("folder", "ifolder", "created", "modified"):
+        setattr(engine, a, getattr(engine, a)[:3])
+    col = vs._col
+    del col.ids[3:], col.payload[3:]
+    assert np.array_equal(engine.x, want[pick]) and all(row is None for row in engine.sp)  # no sparse vector at all
     # more chunks than sparse vectors -> ordinary path (the reference stores the surplus dense-only)
     emb2, sp2, metas2, r2 = store.file_of("t.md", 3)
     vs.store_chunks([(f"t:{i}", e, m) for i, (e, m) in enumerate(zip(emb2, metas2))], sparse_vectors=list(sp2)[:2])
-    assert engine.x.shape[0] == 6 and len(engine.sp[5][0]) == 0 and len(engine.sp[4][0]) > 0
+    assert engine.x.shape[0] == 6 and len(engine.sp[5][0]) == 0 and len(engine.sp[4][0]) > 0 and engine.sp[0] is None
     # references of two different embed_texts calls in one store -> ordinary path, same rows
     e3, s3, m3, r3 = store.file_of("u.md", 2)
     e4, s4, m4, r4 = store.file_of("v.md", 2)

@@ -510,8 +510,6 @@ class VectorStoreService:
                             for c in chunks], np.int64)
         modified = np.array([VR_TS_ABSENT if c[2].source_modified_at is None else int(c[2].source_modified_at)
                              for c in chunks], np.int64)
-        if bm_off is None:  # dense-only store: rows without a sparse vector = empty rows (as in store_chunks above)
-            bm_ids, bm_off = np.zeros(0, np.int32), np.zeros(n + 1, np.int64)
         with col.pending_cv:
             while col.pending_rows > self._MAX_PENDING_ROWS and not col.stopped and col.deferred_error is None:
                 col.pending_cv.wait(0.05)
@@ -523,7 +521,8 @@ class VectorStoreService:
                 ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
             entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(),
                          wp_ids=np.asarray(wp_ids, np.int32), wp_off=np.asarray(wp_off, np.int64),
-                         bm_ids=np.asarray(bm_ids, np.int32), bm_off=np.asarray(bm_off, np.int64),
+                         bm_ids=None if bm_off is None else np.asarray(bm_ids, np.int32),  # None: a dense-only store
+                         bm_off=None if bm_off is None else np.asarray(bm_off, np.int64),
                          folder=folder, ifolder=ifolder, created=created, modified=modified)
             with col.pending_cv:
                 if col.stopped:
@@ -558,8 +557,9 @@ class VectorStoreService:
                 with col.pending_cv:
                     later, col.pending, col.pending_rows = col.pending, [], 0
                     col.deferred_error = e
-                for b in reversed(batch + later):  # none of these rows reached the engine: take them back, newest first
-                    cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
+                for b in reversed(batch + later):  # rows that did not reach the engine: taken back, newest first
+                    if not b.get("done"):
+                        cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
             finally:
                 with col.pending_cv:
                     col.flushing = False
@@ -567,23 +567,36 @@ class VectorStoreService:
 
     @staticmethod
     def _flush(col: _Collection, batch: list[dict]) -> None:
+        """One fused engine call per run of consecutive stores of the same kind (with / without sparse vectors: points
+        stored without one do not count towards the BM25 statistics, so the two kinds cannot share a call)."""
         engine = batch[0]["engine"]
-        cat = lambda key: batch[0][key] if len(batch) == 1 else np.concatenate([b[key] for b in batch])  # noqa: E731
+        a = 0
+        while a < len(batch):
+            b = a + 1
+            while b < len(batch) and (batch[b]["bm_off"] is None) == (batch[a]["bm_off"] is None):
+                b += 1
+            run = batch[a:b]
+            cat = lambda key: run[0][key] if len(run) == 1 else np.concatenate([r[key] for r in run])  # noqa: E731,B023
 
-        def offsets(key):
-            if len(batch) == 1:
-                return batch[0][key]
-            out, base = [batch[0][key]], int(batch[0][key][-1])
-            for b in batch[1:]:
-                out.append(b[key][1:] + base)
-                base += int(b[key][-1])
-            return np.concatenate(out)
+            def offsets(key):
+                if len(run) == 1:  # noqa: B023
+                    return run[0][key]  # noqa: B023
+                out, base = [run[0][key]], int(run[0][key][-1])  # noqa: B023
+                for r in run[1:]:  # noqa: B023
+                    out.append(r[key][1:] + base)
+                    base += int(r[key][-1])
+                return np.concatenate(out)
 
-        got = engine.index_batch(cat("wp_ids"), offsets("wp_off").astype(np.int32), cat("bm_ids"), offsets("bm_off"),
-                                 folder_ids=cat("folder"), index_folder_ids=cat("ifolder"),
-                                 created=cat("created"), modified=cat("modified"))
-        if got != batch[0]["first"]:
-            raise RuntimeError(f"host table and engine rows diverged ({batch[0]['first']} vs {got})")
+            sparse = run[0]["bm_off"] is not None
+            got = engine.index_batch(cat("wp_ids"), offsets("wp_off").astype(np.int32),
+                                     cat("bm_ids") if sparse else None, offsets("bm_off") if sparse else None,
+                                     folder_ids=cat("folder"), index_folder_ids=cat("ifolder"),
+                                     created=cat("created"), modified=cat("modified"))
+            if got != run[0]["first"]:
+                raise RuntimeError(f"host table and engine rows diverged ({run[0]['first']} vs {got})")
+            for r in run:
+                r["done"] = True
+            a = b
 
     @staticmethod
     def _raise_deferred_error(col: _Collection) -> None:
