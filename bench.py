@@ -52,9 +52,13 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=8)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--batch", type=int, default=2048, help="chunks per step per GPU")
+    p.add_argument("--batch", type=int, default=2200,
+                   help="chunks per step per GPU (2200 x ~118 tokens = ~1014 row tiles of 256: the N=768 GEMMs then fill "
+                        "11.9 of 12 rounds of the 256 CUs instead of 11.06 of 12 at 2048)")
     p.add_argument("--corpus", type=int, default=1_000_000, help="pre-populated rows per GPU")
     p.add_argument("--queries", type=int, default=1000)
+    p.add_argument("--dropin-files", type=int, default=2000,
+                   help="synthetic documents pushed through the reference's unmodified per-file call sequence (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16"],
@@ -142,6 +146,131 @@ def populate(torch, gen, dev, engine, rows, dim):
         engine.upsert(x, sparse=(off, ids.to(torch.int32).reshape(-1).contiguous(), val))
         keep.append(x)
     return keep
+
+
+def synthetic_vocab(rng, size):
+    """A WordPiece vocabulary of exactly ``size`` entries: specials, single characters, '##' characters, random words."""
+    letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("abcdefghijklmnopqrstuvwxyz0123456789.,!?:;'-")
+    vocab += ["##" + c for c in "abcdefghijklmnopqrstuvwxyz0123456789"]
+    words: dict = {}
+    while len(vocab) + len(words) < size:
+        for w in ("".join(rng.choice(letters, size=int(rng.integers(2, 8)))) for _ in range(4096)):
+            if len(vocab) + len(words) < size and w not in words and len(w) > 1:
+                words[w] = True
+    words = list(words)
+    # [CLS] / [SEP] must sit where the bench's device-made batches put them (ids 101 / 102), as in BERT's vocab.txt
+    vocab = vocab + words
+    for tok, at in (("[CLS]", 101), ("[SEP]", 102)):
+        i = vocab.index(tok)
+        vocab[i], vocab[at] = vocab[at], vocab[i]
+    return vocab, words
+
+
+def synthetic_documents(rng, words, n_files):
+    """Parsed files as IndexingService sees them: 3..40 paragraphs of 1..4 sentences of 5..24 words."""
+    warr = np.array(words)
+    docs = []
+    for _ in range(n_files):
+        paras = []
+        for _ in range(int(rng.integers(3, 40))):
+            n_sent = int(rng.integers(1, 5))
+            lens = rng.integers(5, 25, size=n_sent)
+            ws = warr[rng.integers(0, len(warr), size=int(lens.sum()))]
+            sents, a = [], 0
+            for ln in lens:
+                sents.append(" ".join(ws[a:a + ln]).capitalize() + ".")
+                a += ln
+            paras.append(" ".join(sents))
+        docs.append("\n\n".join(paras))
+    return docs
+
+
+def mirror_engine_rows(vs, n_rows):
+    """Host-table rows for engine rows that were appended BELOW the service (the device-made corpus and the timed
+    index_batch steps), so that VectorStoreService can resolve any row a search returns."""
+    col = vs._col
+    have = len(col.ids)
+    if n_rows > have:
+        payload = vs._payload_of("synthetic corpus row", _placeholder_meta())
+        vs._append_host_rows(col, [f"synthetic-{i}" for i in range(have, n_rows)], [payload] * (n_rows - have))
+
+
+def _placeholder_meta():
+    from voitta_rag_amd.vector_store import ChunkMetadata
+
+    return ChunkMetadata(file_path="synthetic/corpus.bin", folder_path="synthetic", index_folder="synthetic",
+                         file_name="corpus.bin", chunk_index=0, total_chunks=1, start_char=0, end_char=0, indexed_at="t")
+
+
+def dropin_section(args, engine, state, rng):
+    """The reference's own caller code on the native classes, unmodified:
+      indexing  IndexingService._index_file_standard (indexing.py:513-563): chunk_text -> embed_texts -> sparse
+                embed_texts -> zip -> store_chunks, one file at a time, from raw text;
+      query     mcp_server.py:469-485: embed_query(text) -> sparse embed_query(text) -> VectorStoreService.search
+    on the engine that holds the >= 1M-row corpus. Returns (chunks/s, chunks, files, p50 ms, p99 ms)."""
+    import tempfile
+
+    from voitta_rag_amd import config, embedding, sparse_embedding, store_registry, vector_store
+    from voitta_rag_amd import encoder as enc
+    from voitta_rag_amd.chunking import get_chunking_service
+    from voitta_rag_amd.vector_store import ChunkMetadata
+    from voitta_rag_amd.wordpiece import WordPieceTokenizer
+
+    vocab, words = synthetic_vocab(rng, MODEL["vocab"])
+    d = tempfile.mkdtemp(prefix="voitta-bench-")
+    with open(os.path.join(d, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(vocab) + "\n")
+    os.environ["EMBEDDING_DIMENSION"] = str(MODEL["hidden"])
+    os.environ["EMBEDDING_MODEL"] = MODEL["name"]  # (no "e5" in the name: no prefixes, as for bge)
+    config.get_settings.cache_clear()
+    store_registry.set_engine(engine)
+    desc = enc.BertDesc(MODEL["layers"], MODEL["hidden"], MODEL["heads"], MODEL["intermediate"], vocab=MODEL["vocab"],
+                        max_pos=MODEL["max_pos"], pooling=MODEL["pooling"], normalize=True, precision=args.precision)
+    emb = embedding.EmbeddingService()
+    emb._model = embedding.NativeSentenceEncoder(engine, desc, state, WordPieceTokenizer.from_pretrained(d), MODEL["max_pos"])
+    embedding._embedding_service = emb
+    sp = sparse_embedding.get_sparse_embedding_service()
+    vs = vector_store.VectorStoreService()
+    mirror_engine_rows(vs, engine.count()[0])
+    chunker = get_chunking_service()
+    docs = synthetic_documents(rng, words, args.dropin_files + 40)
+
+    def index_file(i, content):
+        chunks = chunker.chunk_text(content)
+        texts = [c.text for c in chunks]
+        embeddings = emb.embed_texts(texts)
+        sparse_vectors = sp.embed_texts(texts)
+        fp = f"dir{i % 7}/f{i}.md"
+        chunk_data = [(c.text, e, ChunkMetadata(file_path=fp, folder_path=f"dir{i % 7}", index_folder=f"dir{i % 7}",
+                                                file_name=f"f{i}.md", chunk_index=c.index, total_chunks=len(chunks),
+                                                start_char=c.start_char, end_char=c.end_char, indexed_at="t",
+                                                source_modified_at=1_700_000_000 + i))
+                      for c, e in zip(chunks, embeddings)]
+        vs.store_chunks(chunk_data, sparse_vectors=sparse_vectors)
+        return len(chunks)
+
+    for i in range(40):  # warm-up: flusher thread, table growth, graphs
+        index_file(i, docs[i])
+    vs.flush()
+    engine.sync()
+    t0 = time.perf_counter()
+    n_chunks = sum(index_file(40 + i, docs[40 + i]) for i in range(args.dropin_files))
+    vs.flush()  # every row searchable
+    engine.sync()
+    dt = time.perf_counter() - t0
+
+    warr = np.array(words)
+    questions = [" ".join(warr[rng.integers(0, len(warr), size=int(rng.integers(5, 12)))]) + "?" for _ in range(220)]
+    lat = np.empty(200)
+    for i, q in enumerate(questions):
+        t1 = time.perf_counter()
+        got = vs.search(emb.embed_query(q), limit=10, sparse_query=sp.embed_query(q), sparse_weight=0.1)
+        if i >= 20:
+            lat[i - 20] = time.perf_counter() - t1
+        assert len(got) == 10
+    store_registry.set_engine(None)  # (the engine stays ours to close)
+    return n_chunks / dt, n_chunks, args.dropin_files, float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3)
 
 
 def pmc_traffic(kernel_prefix: str):
@@ -258,11 +387,11 @@ def main():
 
     dim = MODEL["hidden"]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    engine = Engine(dim, device=local_rank, initial_rows=args.corpus + (args.steps + args.warmup) * args.batch + 64)
+    engine = Engine(dim, device=local_rank, initial_rows=args.corpus + (args.steps + args.warmup) * args.batch + (args.dropin_files + 40) * 32 + 64)
+    state = random_state(torch, gen, dev)
     enc.load_encoder(engine, enc.BertDesc(MODEL["layers"], dim, MODEL["heads"], MODEL["intermediate"],
                                           vocab=MODEL["vocab"], max_pos=MODEL["max_pos"], pooling=MODEL["pooling"],
-                                          precision=args.precision),
-                     random_state(torch, gen, dev))
+                                          precision=args.precision), state)
     corpus_chunks = populate(torch, gen, dev, engine, args.corpus, dim)
     batches = [make_batch(torch, gen, dev, args.batch, i) for i in range(args.warmup + args.steps)]
     torch.cuda.synchronize()
@@ -328,6 +457,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         p50, p99 = float(t[0]), float(t[1])
     dense_only = [engine.search_dense(qs_host[20 + i: 21 + i], 10) for i in range(min(50, args.queries))]
+
+    # ---- batched queries: all --queries dense top-10 searches in ONE call -----------
+    # host arrays in, host arrays out (queries up, rows + scores down are inside the timed region)
+    qb = np.ascontiguousarray(qs_host[20:20 + args.queries])
+    batch_call = (lambda: searcher.search_dense_batch(qb, 10)) if world > 1 else (lambda: engine.search_dense(qb, 10))
+    for _ in range(2):
+        batched = batch_call()
+    engine.profile(True)
+    barrier()
+    t1 = time.perf_counter()
+    batch_reps = 5
+    for _ in range(batch_reps):
+        batched = batch_call()
+    barrier()
+    batch_dt = time.perf_counter() - t1
+    bscan_ms, bscan_n, bscan_ops = engine.profile_read(Engine.PROF_BATCH_SCAN)
+    engine.profile(False)
+    if world > 1:
+        t = torch.tensor([batch_dt], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        batch_dt = float(t.item())
+    qps_batched = batch_reps * args.queries / batch_dt
     # the same query when it arrives as TEXT: WordPiece ids of a short question (12 tokens) are encoded by
     # the engine first (embed_query's path, embedding.py:76-86), then searched — single GPU only
     enc_lat = full_lat = None
@@ -357,7 +508,24 @@ def main():
             got = got[got < args.corpus]  # rows indexed by the timed steps are not in `xs`
             hits += len(set(ref.tolist()) & set(got.tolist()))
         recall = hits / (10.0 * nq)
+        recall_batched = None
+        if world == 1:
+            hits = 0
+            for i in range(nq):
+                ref = torch.topk(xs @ qs[20 + i], 10).indices.cpu().numpy()
+                got = np.asarray(batched[i][0])
+                got = got[got < args.corpus]
+                hits += len(set(ref.tolist()) & set(got.tolist()))
+            recall_batched = hits / (10.0 * nq)
+        del xs
     del corpus_chunks
+    torch.cuda.empty_cache()
+
+    # ---- the reference's unmodified caller sequences on the native classes ---------
+    dropin = None
+    if world == 1 and args.dropin_files > 0:
+        dropin = dropin_section(args, engine, state, np.random.default_rng(17))
+    del state
 
     if rank == 0:
         gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -379,10 +547,10 @@ def main():
             "dtype": {"f32": "f32",
                       "f16x3": "f16x3 (operands as hi+lo f16 = 22 significant bits, three f16-MFMA passes, f32 "
                                "accumulate; measured |1-cos| ~5e-8 vs the f64 oracle)",
-                      "f16": "f16 (f16 MFMA operands, f32 accumulate; attention, softmax, residual stream, pooling in f32; "
-                             "LayerNorm statistics in f32, applied inside the GEMM epilogues; "
-                             "measured |1-cos| = 1e-6..2e-6 vs the f64 oracle on the full 12-layer shape (tests/test_encoder_gpu.py), "
-                             "north_star tolerance 1e-4)"
+                      "f16": "f16 (f16 MFMA operands, f32 accumulate; softmax, LayerNorm statistics and pooling in f32; the "
+                             "residual stream between layers is stored as f16 (LayerNorm is applied inside the GEMM epilogues from "
+                             "f32 row sums); measured |1-cos| <= 2e-6 vs the f64 oracle on the full 12-layer shape "
+                             "(tests/test_encoder_gpu.py), north_star tolerance 1e-4)"
                       }[args.precision],
             "data": "synthetic (seeded token ids / unit vectors; random-init N(0,0.02) weights of the named shape)",
             "config": {
@@ -402,21 +570,37 @@ def main():
             "p50_query_from_tokens_ms": None if full_lat is None else round(full_lat, 4),
             "query_from_tokens_kind": "the same search with the 12-token query embedded by the engine first (vr_encode + vr_search_hybrid)",
             "recall_at_10_dense_vs_torch_matmul": recall,
+            "qps_batched_1k": round(qps_batched, 1),
+            "batched_kind": f"{args.queries} dense top-10 queries per call (vr_search_dense, host arrays in and out), "
+                            f"{batch_reps} calls timed; answers bit-identical to the single-query path (tests/test_search_gpu.py, "
+                            "tests/test_fullsize_gpu.py)",
+            "ms_per_batched_call": round(batch_dt / batch_reps * 1e3, 3),
+            "recall_at_10_batched_vs_torch_matmul": recall_batched,
+            "dropin_index_chunks_per_s": None if dropin is None else round(dropin[0], 1),
+            "dropin_kind": None if dropin is None else
+                f"{dropin[2]} synthetic documents ({dropin[1]} chunks) from raw text through the reference's per-file sequence "
+                "chunk_text -> embed_texts -> sparse embed_texts -> zip -> store_chunks (indexing.py:513-563) on the drop-in "
+                "classes, one thread, until every row is searchable (write-behind: voitta_rag_amd/deferred.py)",
+            "p50_query_from_text_ms": None if dropin is None else round(dropin[3], 4),
+            "p99_query_from_text_ms": None if dropin is None else round(dropin[4], 4),
+            "query_from_text_kind": "embed_query(text) -> sparse embed_query(text) -> VectorStoreService.search(limit=10, hybrid) "
+                                    "as mcp_server.py:469-485 calls them, StoredChunk objects out; corpus as above",
             # f32: algorithmic FLOP against the f32-MFMA peak. f16x3: every algorithmic multiply-add is
             # three f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOP/s is the dense f16 peak / 3.
             "roofline": {
                 "kernel": {"f32": "vr::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                            "f16x3": "vr::gemm_f16x3_256_kernel<EPI, 3> (v_mfma_f32_16x16x32_f16, 3 passes per "
                                     "product; 256x256 tiles)",
-                           "f16": "vr::gemm_f16x3_256_kernel<EPI, 1> (v_mfma_f32_16x16x32_f16, one pass; "
-                                  "256x256x64 tiles)"}[args.precision],
+                           "f16": "vr::gemm_f16_pp_kernel<EPI> (v_mfma_f32_16x16x32_f16, one pass; 256x256x64 tiles, "
+                                  "8 waves in two phase-shifted groups)"}[args.precision],
                 "bound": "mfma",
                 "achieved": round(gemm_tf, 2),
                 "peak": gemm_peak,
                 "unit": "TFLOP/s",
                 "frac": round(gemm_tf / gemm_peak, 4),
                 "executed_mfma_TFLOPs": round(gemm_tf * (3 if args.precision == "f16x3" else 1), 1),
-                "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "f32" else "gemm_f16x3_256_kernel"),
+                "traffic": pmc_traffic({"f32": "gemm_f32_kernel", "f16x3": "gemm_f16x3_256_kernel",
+                                        "f16": "gemm_f16_pp_kernel"}[args.precision]),
                 "algorithmic_flop_per_launch": round(gemm_flop / max(gemm_n, 1)),
                 "launches": gemm_n,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
@@ -440,6 +624,19 @@ def main():
                 "avg_launch_ms": round(scan_ms / max(scan_n, 1), 4),
                 "sparse_scan_avg_ms": round(sp_ms / max(sp_n, 1), 4),
                 "sparse_scan_GBps": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1) if sp_ms > 0 else None,
+            },
+            "roofline_batched_search": {
+                "kernel": "vr::batch_scan_kernel<PASS> (v_mfma_i32_16x16x64_i8: int8 shadow corpus x int8 query parts, two passes: "
+                          "per-slab maxima for the thresholds, then candidates; exact f32 re-score of the candidates)",
+                "bound": "mfma",
+                "achieved": round(bscan_ops / (bscan_ms * 1e-3) / 1e12, 2) if bscan_ms > 0 else None,
+                "peak": 2 * PEAK_F16_MFMA_TFLOPS,
+                "unit": "TOP/s (int8; algorithmic 2*N*D*Q per launch)",
+                "frac": round(bscan_ops / (bscan_ms * 1e-3) / 1e12 / (2 * PEAK_F16_MFMA_TFLOPS), 4) if bscan_ms > 0 else None,
+                "launches": bscan_n,
+                "avg_launch_ms": round(bscan_ms / max(bscan_n, 1), 4),
+                "share_of_call_time": round(bscan_ms * 1e-3 / batch_dt, 4),
+                "traffic": pmc_traffic("batch_scan_kernel"),
             },
             "attention": {"avg_launch_ms": round(attn_ms / max(attn_n, 1), 4),
                           "TFLOPs": round(attn_flop / (attn_ms * 1e-3) / 1e12, 2) if attn_ms > 0 else None},
