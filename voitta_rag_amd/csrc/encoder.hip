@@ -1105,9 +1105,23 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #undef VR_GLDS_STAGE
 }
 
+// The epilogue of the f16 kernels whose MFMAs take the WEIGHT fragment as their A operand (gemm_f16_pp_kernel,
+// gemm_f16_d2_kernel), straight from the accumulators of a wave's 128-token x 64-feature tile at token row
+// `row0`, feature `col0`: acc[i][j][r] of lane (t = lane & 15, g = lane >> 4) is token row 16 i + t, feature 4 g + r of
+// weight fragment j — four CONSECUTIVE features of one token — and the W image was staged with its rows permuted so
+// that fragments 2p and 2p + 1 hold features 32 p + 8 g + {0..3} and {4..7}: a lane owns 8 consecutive features per
+// fragment pair = one 16-byte f16 store (or two 16-byte f32 stores), 64 contiguous bytes per token and instruction
+// across the four lane groups. No transpose through LDS (it cost 128 ds_write_b32 + 32 ds_read_b128 per wave and
+// tile, about half of the f16-output epilogue) and no LDS use at all.
+// FULL: the wave's tile lies inside the matrix, nothing is predicated. This is not about the compares: a store under
+// `if (ok)` sits in its own basic block, the waits the compiler places for the loads that are in flight across it
+// (bias, residual rows) are then merged over both paths into vmcnt(0) — and on gfx950 vmcnt counts STORES too, so every
+// store waited for the one before it: one 1 KiB store in flight per wave, the epilogue latency-bound. In straight-line
+// code the counts are exact and the stores stay in flight.
 // Diagnostic build only (make diag -> libvoitta_engine_diag.so, selected with VOITTA_ENGINE_LIB): VR_GEMM_DIAG in the
 // environment switches parts of gemm_f16_pp_kernel off at run time, so that one box can time the kernel without
-// its loads (1), its epilogue (2), its MFMAs (4), its fragment reads (8) or its barriers (16). Results are then
+// its loads (1), its epilogue (2), its MFMAs (4), its fragment reads (8), its barriers (16), the epilogue's
+// stores (32: arithmetic only) or the epilogue's arithmetic (64: stores of the raw accumulators only). Results are then
 // wrong by construction; only the timings mean anything. The shipped library compiles none of this.
 #ifdef VR_GEMM_DIAG_BUILD
 __device__ int g_gemm_diag = 0;
@@ -1115,6 +1129,179 @@ __device__ int g_gemm_diag = 0;
 #else
 #define VR_DIAG(bit) false
 #endif
+
+constexpr int kWaveStatHalfs = 128 * 4;  // 128 float2 per wave (direct_epilogue's row statistics), in halfs
+
+template <int EPI, bool FULL>
+__device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane,
+                                                const float* __restrict__ bias, const float* __restrict__ R,
+                                                float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl,
+                                                int M, int N, float unscale, const float2* __restrict__ ln_stat,
+                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                float2* wave_stat) {
+  const int tok = lane & 15, fg = lane >> 4;
+#ifdef VR_GEMM_DIAG_BUILD
+  const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
+#endif
+  const int fbase = col0 + 8 * fg;  // + 32 p (+ 4 q): this lane's features
+  // FULL tiles address everything as (wave-uniform pointer) + (one 32-bit lane offset): the uniform part — row
+  // 16 pc of the tile, column col0 + 32 p2 — lives in scalar registers, where per-lane 64-bit addresses of eight pieces
+  // did not fit next to the accumulators. (A chunk's matrices stay below 4 GiB: kMaxChunkTokens.)
+  const uint32_t loff = static_cast<uint32_t>(tok * N + 8 * fg);
+  auto upiece = [&](auto* base, int pc, int col) { return base + (static_cast<int64_t>(row0 + 16 * pc) * N + col); };
+  constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
+  constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS || EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16 ||
+                          EPI == EPI_RLS_R16_O32;
+  constexpr bool kR16 = EPI == EPI_RLS_R16_O16 || EPI == EPI_RLS_R16_O32;   // residual rows are f16
+  constexpr bool kNoOut32 = EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16;  // pre-LN rows go out as f16 only
+  constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
+  constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
+  constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
+  constexpr bool kHalfOut = kGelu || EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16 || kNoOut32;
+  // fragment pair p2 (features fbase + 32 p2 .. + 7) outside, the eight 16-token pieces inside: the column
+  // vectors (bias, LayerNorm gain / shift or column sums) of one pair stay in registers, not those of all four
+  // fragments (which, with the residual rows in flight, did not fit next to the 128 accumulators)
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2) {
+    const int c0 = fbase + 32 * p2;
+    const bool col_ok = FULL || c0 < N;  // N % 8 == 0: a lane's eight features are in or out together
+    const int cs = col_ok ? c0 : 0;
+    float4 b4[2], lg4[2] = {}, lb4[2] = {};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t lc = static_cast<uint32_t>(8 * fg + 4 * q);
+      const int uc = col0 + 32 * p2;
+      b4[q] = FULL ? *reinterpret_cast<const float4*>(bias + uc + lc) : *reinterpret_cast<const float4*>(bias + cs + 4 * q);
+      if (kResidLN || kFold)
+        lg4[q] = FULL ? *reinterpret_cast<const float4*>(ln_g + uc + lc) : *reinterpret_cast<const float4*>(ln_g + cs + 4 * q);
+      if (kResidLN)
+        lb4[q] = FULL ? *reinterpret_cast<const float4*>(ln_b + uc + lc) : *reinterpret_cast<const float4*>(ln_b + cs + 4 * q);
+    }
+    // residual rows (and row statistics) of a piece are requested one piece ahead
+    float4 r4[2][2] = {};
+    float2 st2[2] = {};
+    auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
+      if (FULL) {
+        if (kResidual && kR16) {
+          r[0] = *reinterpret_cast<const float4*>(upiece(reinterpret_cast<const half_t*>(R), pc, col0 + 32 * p2) + loff);
+        } else if (kResidual) {
+          r[0] = *reinterpret_cast<const float4*>(upiece(R, pc, col0 + 32 * p2) + loff);
+          r[1] = *reinterpret_cast<const float4*>(upiece(R, pc, col0 + 32 * p2 + 4) + loff);
+        }
+        if (kResidLN || kFold) st = (ln_stat + (row0 + 16 * pc))[static_cast<uint32_t>(tok)];
+        return;
+      }
+      const int64_t rr = min(row0 + 16 * pc + tok, M - 1);
+      if (kResidual && kR16) {  // eight f16 residual values: carried in r[0]'s 16 bytes
+        r[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const half_t*>(R) + rr * N + cs);
+      } else if (kResidual) {
+        r[0] = *reinterpret_cast<const float4*>(R + rr * N + cs);
+        r[1] = *reinterpret_cast<const float4*>(R + rr * N + cs + 4);
+      }
+      if (kResidLN || kFold) st = ln_stat[rr];
+    };
+    if (kResidual || kFold) fetch_residual(0, r4[0], st2[0]);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
+      const int grow = row0 + 16 * pc + tok;
+      if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
+      const bool ok = FULL || (grow < M && col_ok);
+      const float2 st = st2[pc & 1];
+      float v[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+        const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
+        const float lb[4] = {lb4[q].x, lb4[q].y, lb4[q].z, lb4[q].w};
+        const float4 rq = r4[pc & 1][kR16 ? 0 : q];
+        float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
+        if (kR16) {
+          const f16x8 rh = *reinterpret_cast<const f16x8*>(&rq);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rr4[r] = static_cast<float>(rh[4 * q + r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[pc][2 * p2 + q][r];
+          if (VR_DIAG(64)) {
+            v[q][r] = x;
+            continue;
+          }
+          if (kFold)  // inv (acc unscale - mean colsum) + c
+            x = fmaf(fmaf(x, unscale, -(st.x * gg[r])), st.y, bb[r]);
+          else
+            x = x * unscale + bb[r];
+          if (EPI == EPI_BIAS_RESIDUAL) x += rr4[r];
+          if (kResidLN) x += ln_apply(rr4[r], st.x, st.y, gg[r], lb[r]);  // residual = LayerNorm(R row)
+          v[q][r] = x;
+        }
+        if (kGelu && !VR_DIAG(64)) {
+          const f32x2 g01 = gelu_poly2(f32x2{v[q][0], v[q][1]});
+          const f32x2 g23 = gelu_poly2(f32x2{v[q][2], v[q][3]});
+          v[q][0] = g01.x, v[q][1] = g01.y, v[q][2] = g23.x, v[q][3] = g23.y;
+        }
+      }
+      if (kHalfOut || kStats) {  // f16 row: 8 consecutive features, one 16-byte store
+        f16x8 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = static_cast<half_t>(fminf(fmaxf(v[0][r], -65504.0f), 65504.0f));
+          h[4 + r] = static_cast<half_t>(fminf(fmaxf(v[1][r], -65504.0f), 65504.0f));
+        }
+        if (VR_DIAG(32)) {
+          if (h[0] == static_cast<half_t>(123.0f) && h[7] == static_cast<half_t>(77.0f)) Ch[0] = h[3];  // (keeps the arithmetic alive)
+        } else if (FULL)
+          *reinterpret_cast<f16x8*>(upiece(Ch, pc, col0 + 32 * p2) + loff) = h;
+        else if (ok)
+          *reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow) * N + c0) = h;
+      }
+      if (!kHalfOut && FULL) {  // f32 row
+        *reinterpret_cast<float4*>(upiece(C, pc, col0 + 32 * p2) + loff) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+        *reinterpret_cast<float4*>(upiece(C, pc, col0 + 32 * p2 + 4) + loff) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+      } else if (!kHalfOut && ok) {
+        *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+        *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0 + 4) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+      }
+      if (kStats) {
+        // this wave's 64 columns of every pre-LayerNorm row contribute a (sum, sum of squares) to the row's statistics:
+        // 8 values per lane and fragment pair, the other 24 of the pair in the three other lane groups. The first
+        // pair's sums wait in `wave_stat` (128 float2 of LDS that only this wave touches) for the second's — sixteen
+        // registers per lane less than carrying them, which the branch-free form of this code did not have.
+        float a1 = 0.0f, a2 = 0.0f;
+        if (col_ok) {
+          a1 = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+          a2 = ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
+               ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
+        }
+        a1 += __shfl_xor(a1, 16);
+        a2 += __shfl_xor(a2, 16);
+        a1 += __shfl_xor(a1, 32);
+        a2 += __shfl_xor(a2, 32);
+        if (p2 == 0) {
+          if (fg == 0) wave_stat[16 * pc + tok] = make_float2(a1, a2);
+        } else {
+          const float2 first = wave_stat[16 * pc + tok];
+          a1 += first.x;
+          a2 += first.y;
+          const int seg = col0 >> 6;
+          if (FULL) {
+            if (fg == 0)
+              (reinterpret_cast<float2*>(Cl) + (static_cast<int64_t>(row0 + 16 * pc) * (N >> 6) + seg))[static_cast<uint32_t>(tok * (N >> 6))] =
+                  make_float2(a1, a2);
+          } else if (fg == 0 && grow < M && seg < (N >> 6)) {
+            reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(a1, a2);
+          }
+        }
+      }
+      // Every piece stays a basic block of its own: in one long block the SLP vectoriser pairs up the arithmetic of
+      // DIFFERENT pieces (v_pk_* over values of two pieces), all eight pieces are then in flight at once and a
+      // thousand registers spill. The never-taken branch below (M is positive; the compiler cannot know) ends the
+      // block without putting anything that counts in vmcnt on a side path, so the wait counts stay exact.
+      if (FULL && M < 0) asm volatile("s_nop 0");
+    }
+  }
+}
+
 
 // ---- the 256x256 f16 product with a ping-pong main loop ----------------------------------------------
 //
@@ -1143,7 +1330,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
     int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
     const float* __restrict__ ln_b, int stagger_sleeps) {
-  __shared__ half_t lds[2 * kStageHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
+  __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
   const int tiles_n = (N + GBN - 1) / GBN;
   const int tiles_m = (M + GBM - 1) / GBM;
   const int total = tiles_m * tiles_n;
@@ -1166,6 +1353,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  float2* wave_stat = reinterpret_cast<float2*>(lds + 2 * kStageHalfs + wave * kWaveStatHalfs);
   // Phase diversity: every block's tile takes the same time, so without this all 256 CUs reach their
   // epilogues together — a burst of stores at the chip's store bandwidth with every matrix pipe idle,
   // followed by a main loop with the store path idle. Block `local` (of G) starts local / G of
@@ -1376,121 +1564,14 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     // wait for the stores too).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!VR_DIAG(2)) {
-    const int tok = lane & 15, fg = lane >> 4;
-    const int fbase = bn + wn * 64 + 8 * fg;  // + 32 p (+ 4 q): this lane's features
-    constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
-    constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS || EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16 ||
-                            EPI == EPI_RLS_R16_O32;
-    constexpr bool kR16 = EPI == EPI_RLS_R16_O16 || EPI == EPI_RLS_R16_O32;   // residual rows are f16
-    constexpr bool kNoOut32 = EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16;  // pre-LN rows go out as f16 only
-    constexpr bool kResidLN = EPI == EPI_BIAS_RESIDUAL_LN || kStats;
-    constexpr bool kResidual = EPI == EPI_BIAS_RESIDUAL || kResidLN;
-    constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
-    constexpr bool kHalfOut = kGelu || EPI == EPI_BIAS_F16 || EPI == EPI_FOLD_F16 || kNoOut32;
-    float s1[8], s2[8];  // kStats: this lane's share of the row sums, per piece
-#pragma unroll
-    for (int pc = 0; pc < 8; ++pc) s1[pc] = s2[pc] = 0.0f;
-    // fragment pair p2 (features fbase + 32 p2 .. + 7) outside, the eight 16-token pieces inside: the column
-    // vectors (bias, LayerNorm gain / shift or column sums) of one pair stay in registers, not those of all four
-    // fragments (which, with the residual rows in flight, did not fit next to the 128 accumulators)
-#pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) {
-      const int c0 = fbase + 32 * p2;
-      const bool col_ok = c0 < N;  // N % 8 == 0: a lane's eight features are in or out together
-      const int cs = col_ok ? c0 : 0;
-      float4 b4[2], lg4[2] = {}, lb4[2] = {};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        b4[q] = *reinterpret_cast<const float4*>(bias + cs + 4 * q);
-        if (kResidLN || kFold) lg4[q] = *reinterpret_cast<const float4*>(ln_g + cs + 4 * q);
-        if (kResidLN) lb4[q] = *reinterpret_cast<const float4*>(ln_b + cs + 4 * q);
-      }
-      // residual rows (and row statistics) of a piece are requested one piece ahead
-      float4 r4[2][2] = {};
-      float2 st2[2] = {};
-      auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
-        const int64_t rr = min(bm + wm * 128 + 16 * pc + tok, M - 1);
-        if (kResidual && kR16) {  // eight f16 residual values: carried in r[0]'s 16 bytes
-          r[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const half_t*>(R) + rr * N + cs);
-        } else if (kResidual) {
-          r[0] = *reinterpret_cast<const float4*>(R + rr * N + cs);
-          r[1] = *reinterpret_cast<const float4*>(R + rr * N + cs + 4);
-        }
-        if (kResidLN || kFold) st = ln_stat[rr];
-      };
-      if (kResidual || kFold) fetch_residual(0, r4[0], st2[0]);
-#pragma unroll
-      for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
-        const int grow = bm + wm * 128 + 16 * pc + tok;
-        if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
-        const bool ok = grow < M && col_ok;
-        const float2 st = st2[pc & 1];
-        float v[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
-          const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
-          const float lb[4] = {lb4[q].x, lb4[q].y, lb4[q].z, lb4[q].w};
-          const float4 rq = r4[pc & 1][kR16 ? 0 : q];
-          float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
-          if (kR16) {
-            const f16x8 rh = *reinterpret_cast<const f16x8*>(&rq);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rr4[r] = static_cast<float>(rh[4 * q + r]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[pc][2 * p2 + q][r];
-            if (kFold)  // inv (acc unscale - mean colsum) + c
-              x = fmaf(fmaf(x, unscale, -(st.x * gg[r])), st.y, bb[r]);
-            else
-              x = x * unscale + bb[r];
-            if (EPI == EPI_BIAS_RESIDUAL) x += rr4[r];
-            if (kResidLN) x += ln_apply(rr4[r], st.x, st.y, gg[r], lb[r]);  // residual = LayerNorm(R row)
-            v[q][r] = x;
-          }
-          if (kGelu) {
-            const f32x2 g01 = gelu_poly2(f32x2{v[q][0], v[q][1]});
-            const f32x2 g23 = gelu_poly2(f32x2{v[q][2], v[q][3]});
-            v[q][0] = g01.x, v[q][1] = g01.y, v[q][2] = g23.x, v[q][3] = g23.y;
-          }
-        }
-        if (kHalfOut || kStats) {  // f16 row: 8 consecutive features, one 16-byte store
-          f16x8 h;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = static_cast<half_t>(fminf(fmaxf(v[0][r], -65504.0f), 65504.0f));
-            h[4 + r] = static_cast<half_t>(fminf(fmaxf(v[1][r], -65504.0f), 65504.0f));
-          }
-          if (ok) *reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow) * N + c0) = h;
-        }
-        if (!kHalfOut && ok) {  // f32 row
-          *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-          *reinterpret_cast<float4*>(C + static_cast<int64_t>(grow) * N + c0 + 4) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
-        }
-        if (kStats && col_ok) {
-          s1[pc] += ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-          s2[pc] += ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
-                    ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
-        }
-      }
-    }
-    if (kStats) {
-      // this wave's 64 columns of every pre-LayerNorm row contribute a (sum, sum of squares) to the row's
-      // statistics: 16 values per lane (summed above), the other 48 in the three other lane groups
-      const int seg = (bn + wn * 64) >> 6;
-#pragma unroll
-      for (int pc = 0; pc < 8; ++pc) {
-        float a1 = s1[pc], a2 = s2[pc];
-        a1 += __shfl_xor(a1, 16);
-        a2 += __shfl_xor(a2, 16);
-        a1 += __shfl_xor(a1, 32);
-        a2 += __shfl_xor(a2, 32);
-        const int grow = bm + wm * 128 + 16 * pc + tok;
-        if (fg == 0 && grow < M && seg < (N >> 6))
-          reinterpret_cast<float2*>(Cl)[static_cast<int64_t>(grow) * (N >> 6) + seg] = make_float2(a1, a2);
-      }
-    }
+    // (the branch-free form of the epilogues that also read residual rows needs ~30 registers more than this kernel
+    // has left beside its staging state; those keep the predicated form)
+    constexpr bool kBranchFree = EPI != EPI_BIAS_RESIDUAL_LN && EPI != EPI_BIAS_RESIDUAL_LN_STATS && EPI != EPI_RLS_R32_O16 &&
+                                 EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
+    if (kBranchFree && bm + GBM <= M && bn + GBN <= N)  // block-uniform
+      direct_epilogue<EPI, true>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
+    else
+      direct_epilogue<EPI, false>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
     } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
       float t = 0.0f;
       for (int i = 0; i < 8; ++i)
@@ -1501,11 +1582,155 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     tile = next;
     bm = nbm;
     bn = nbn;
+    set_ptrs(bm, bn);  // (again: recomputed here, the eight staging pointers need not stay in registers across the epilogue)
     VR_PP_BARRIER();
     if (wm == 1) VR_PP_BARRIER();  // waves 4-7 fall one segment behind again
   }  // tiles
 #undef VR_PP_BARRIER
 #undef VR_PP_VMCNT4
+}
+
+// ---- the f16 product as TWO INDEPENDENT 256x128 tiles per CU ----------------------------------------------
+//
+// gemm_f16_pp_kernel owns a CU alone (128 KiB of LDS, 8 waves): while its eight waves run the epilogue — at
+// K = 768 the 128 KiB an output tile writes are a third of the tile's time, bound by the CU's store path —
+// the matrix pipes idle, and while they multiply the store path idles. Here a block is FOUR waves (one per
+// SIMD) on a 256-token x 128-feature tile with 72 KiB of LDS, so two blocks share a CU: they are dispatched
+// independently and drift apart, and while one stores its tile the other has the matrix pipes to itself.
+// Inside the K loop the two blocks' waves of a SIMD interleave the way the ping-pong halves do: one reads
+// fragments or waits at its block's barrier while the other multiplies.
+//   * K advances in steps of 32 through a ring of THREE stage buffers (A 256 x 32 + W 128 x 32 halfs = 24 KiB):
+//     step s multiplies out of stage s % 3 while the loads of steps s + 1 and s + 2 are in flight — one
+//     counted vmcnt(6) and one barrier per step (every wave issues 6 direct-to-LDS loads per step);
+//   * rows are 64 bytes in LDS; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 3) (source-side swizzle of
+//     the direct-to-LDS loads), which makes the ds_read_b128 fragment reads conflict-free;
+//   * same wave tile (128 x 64), fragment roles, W row permutation and accumulation order (k ascending) as
+//     gemm_f16_pp_kernel: the result is bit-identical to it, and the epilogue is the same code (direct_epilogue).
+// One tile per block, no persistence: consecutive blocks of an XCD (blockIdx % 8) take the column tiles of one
+// 256-row panel one after the other, so a panel of A is read from HBM once and then from that XCD's L2.
+constexpr int D2M = 256, D2N = 128, D2K = 32;
+constexpr int kD2StageHalfs = (D2M + D2N) * D2K;  // 24 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_d2_kernel(
+    const half_t* __restrict__ Ah, const half_t* __restrict__ Wh, const float* __restrict__ bias,
+    const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
+    int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b) {
+  __shared__ half_t lds[3 * kD2StageHalfs + 4 * kWaveStatHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
+  const int tiles_n = (N + D2N - 1) / D2N;
+  const int tiles_m = (M + D2M - 1) / D2M;
+  const int xcd = static_cast<int>(blockIdx.x) & 7, seq = static_cast<int>(blockIdx.x) >> 3;
+  const int panel = (seq / tiles_n) * 8 + xcd;
+  if (panel >= tiles_m) return;  // block-uniform (the grid is padded to a multiple of 8 panels)
+  const int bm = panel * D2M, bn = (seq % tiles_n) * D2N;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  float2* wave_stat = reinterpret_cast<float2*>(lds + 3 * kD2StageHalfs + wave * kWaveStatHalfs);
+
+  // staging: one direct-to-LDS load moves 16 rows x 64 B; lane -> row (lane >> 2) of the 16, LDS chunk (lane & 3),
+  // source chunk (lane & 3) ^ ((row >> 1) & 3). Wave w stages A rows 16 (w + 4 t) + .. (t = 0..3) and W image rows
+  // 16 (w + 4 t) + .. (t = 0, 1); image row 32 P + 16 q + r holds weight row 32 P + 8 (r >> 2) + 4 q + (r & 3)
+  // (direct_epilogue: a lane then owns 8 consecutive output features).
+  const int srow = lane >> 2;
+  const int schunk = ((lane & 3) ^ ((srow >> 1) & 3)) * 8;
+  const half_t* g_a[4];
+  const half_t* g_w[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    g_a[t] = Ah + static_cast<int64_t>(min(bm + 16 * (wave + 4 * t) + srow, M - 1)) * K + schunk;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int img = 16 * (wave + 4 * t);  // first image row of the instruction: P = img >> 5, q = (img >> 4) & 1
+    const int wrow = (img & ~31) + 8 * (srow >> 2) + 4 * ((img >> 4) & 1) + (srow & 3);
+    g_w[t] = Wh + static_cast<int64_t>(min(bn + wrow, N - 1)) * K + schunk;
+  }
+  const int da = wave * 16 * D2K;               // + 4 t * 16 * D2K
+  const int dw = D2M * D2K + wave * 16 * D2K;   // + 4 t * 16 * D2K
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragments (v_mfma_f32_16x16x32_f16): lane l supplies row (l & 15), k = 8 (l >> 4) + j of the 32-deep step
+  const int frow = lane & 15;
+  const int fk = ((lane >> 4) ^ ((frow >> 1) & 3)) * 8;
+  const int pa = (wm * 128 + frow) * D2K + fk;
+  const int pw = D2M * D2K + (wn * 64 + frow) * D2K + fk;
+  const int nk = K / D2K;
+#ifdef VR_GEMM_DIAG_BUILD
+  const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
+#endif
+
+#define VR_D2_BARRIER()                   \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+  auto issue = [&](half_t* stage, int k0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16(g_a[t] + k0, stage + da + t * 64 * D2K);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) glds16(g_w[t] + k0, stage + dw + t * 64 * D2K);
+  };
+  issue(lds, 0);
+  if (nk > 1) issue(lds + kD2StageHalfs, D2K);
+
+  auto step = [&](auto bsel, int s) {
+    constexpr int B = decltype(bsel)::value;
+    const half_t* st = lds + B * kD2StageHalfs;
+    half_t* nd = lds + ((B + 2) % 3) * kD2StageHalfs;
+    // the loads of step s have landed (those of step s + 1, if any, stay in flight) ...
+    if (s + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VR_D2_BARRIER();  // ... every wave's; and every wave has finished with stage (s - 1) % 3 = (s + 2) % 3
+    if (s + 2 < nk && !VR_DIAG(1)) issue(nd, (s + 2) * D2K);
+    f16x8 af[4], bf[4];  // token rows in two halves of 64: holding all eight fragments did not fit beside acc
+#ifdef VR_GEMM_DIAG_BUILD
+    for (int i = 0; i < 4; ++i) af[i] = bf[i] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (!VR_DIAG(8)) bf[j] = *reinterpret_cast<const f16x8*>(st + pw + j * 16 * D2K);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!VR_DIAG(8)) af[i] = *reinterpret_cast<const f16x8*>(st + pa + (4 * h + i) * 16 * D2K);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!VR_DIAG(4)) acc[4 * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[4 * h + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  int s = 0;
+#pragma clang loop unroll(disable)
+  for (; s + 3 <= nk; s += 3) {
+    step(std::integral_constant<int, 0>{}, s);
+    step(std::integral_constant<int, 1>{}, s + 1);
+    step(std::integral_constant<int, 2>{}, s + 2);
+  }
+  if (s < nk) step(std::integral_constant<int, 0>{}, s);
+  if (s + 1 < nk) step(std::integral_constant<int, 1>{}, s + 1);
+#undef VR_D2_BARRIER
+  if (VR_DIAG(2)) {
+    if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) C[0] = acc[3][1][2];  // (diagnostic) keep the accumulators alive
+    return;
+  }
+  // (EPI_RLS_R32_O16 — layer 0 only — holds two pieces of f32 residual rows: four registers too many without branches)
+  if (EPI != EPI_RLS_R32_O16 && bm + D2M <= M && bn + D2N <= N)  // block-uniform
+    direct_epilogue<EPI, true>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
+  else
+    direct_epilogue<EPI, false>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
 }
 
 // ---- skinny product for M <= 256 rows (one query, a handful of sequences) ---------------------------
@@ -1756,6 +1981,50 @@ static bool pp_usable(int N, int K) {
   return pp_on && K % 128 == 0 && N % 8 == 0;
 }
 
+// gemm_f16_d2_kernel: any K that is a multiple of 32 (the ping-pong kernel needs 128). OFF unless VR_GEMM_D2=1:
+// measured on bge-base, 2200 chunks (profiles/r02_gemm_experiments.md) it runs at 750 TFLOP/s against the ping-pong
+// kernel's 930 — its epilogues do overlap the other block's main loop, but 32-deep stages of a 256x128 tile pull
+// 1.5x the bytes through L2 -> LDS in 64-byte row segments, and that path (14.5 TB/s here) is what bounds it.
+static bool d2_usable(int N, int K) {
+  static const bool d2_on = getenv("VR_GEMM_D2") && atoi(getenv("VR_GEMM_D2")) == 1;
+  return d2_on && K % D2K == 0 && N % 8 == 0;
+}
+
+// the kernels whose epilogue is direct_epilogue (all EPI_* variants, f16 residual stream included)
+static bool direct_usable(int N, int K) { return d2_usable(N, K) || pp_usable(N, K); }
+
+static void launch_d2(int epi, hipStream_t s, const half_t* Ah, const half_t* Wh, const float* bias, const float* R,
+                      float* C, half_t* Ch, half_t* Cl, int M, int N, int K, float unscale, const float2* ln_stat,
+                      const float* ln_g, const float* ln_b) {
+  const int tiles_m = (M + D2M - 1) / D2M, tiles_n = (N + D2N - 1) / D2N;
+  const int grid = (tiles_m + 7) / 8 * 8 * tiles_n;
+#ifdef VR_GEMM_DIAG_BUILD
+  static bool diag_set = false;
+  if (!diag_set) {
+    const int v = getenv("VR_GEMM_DIAG") ? atoi(getenv("VR_GEMM_DIAG")) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_diag), &v, sizeof(int));
+    diag_set = true;
+  }
+#endif
+#define VR_LAUNCH_D2(E)                                                                                       \
+  hipLaunchKernelGGL((gemm_f16_d2_kernel<E>), dim3(grid), dim3(256), 0, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, \
+                     unscale, ln_stat, ln_g, ln_b)
+  switch (epi) {
+    case EPI_BIAS: VR_LAUNCH_D2(EPI_BIAS); break;
+    case EPI_BIAS_GELU: VR_LAUNCH_D2(EPI_BIAS_GELU); break;
+    case EPI_BIAS_F16: VR_LAUNCH_D2(EPI_BIAS_F16); break;
+    case EPI_BIAS_RESIDUAL_LN: VR_LAUNCH_D2(EPI_BIAS_RESIDUAL_LN); break;
+    case EPI_FOLD_F16: VR_LAUNCH_D2(EPI_FOLD_F16); break;
+    case EPI_FOLD_GELU: VR_LAUNCH_D2(EPI_FOLD_GELU); break;
+    case EPI_BIAS_RESIDUAL_LN_STATS: VR_LAUNCH_D2(EPI_BIAS_RESIDUAL_LN_STATS); break;
+    case EPI_RLS_R32_O16: VR_LAUNCH_D2(EPI_RLS_R32_O16); break;
+    case EPI_RLS_R16_O16: VR_LAUNCH_D2(EPI_RLS_R16_O16); break;
+    case EPI_RLS_R16_O32: VR_LAUNCH_D2(EPI_RLS_R16_O32); break;
+    default: VR_LAUNCH_D2(EPI_BIAS_RESIDUAL); break;
+  }
+#undef VR_LAUNCH_D2
+}
+
 static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const half_t* Wh, const float* bias,
                       const float* R, float* C, half_t* Ch, half_t* Cl, int M, int N, int K, float unscale,
                       const float2* ln_stat, const float* ln_g, const float* ln_b) {
@@ -1994,7 +2263,9 @@ static int launch_gemm_f16x3(vr_engine* e, int epi, const half_t* Ah, const half
     }
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     const int grid256 = std::min(tiles, n_cu);
-    if (passes == 1 && pp_usable(N, K))  // f16 mode: the ping-pong main loop (gemm_f16_pp_kernel)
+    if (passes == 1 && d2_usable(N, K))  // f16 mode: two independent half-width tiles per CU (gemm_f16_d2_kernel)
+      launch_d2(epi, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
+    else if (passes == 1 && pp_usable(N, K))  // the ping-pong main loop (gemm_f16_pp_kernel)
       launch_pp(epi, grid256, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
     else if (passes == 1)
       launch_256<1>(epi, grid256, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, unscale, ln_stat, ln_g, ln_b);
@@ -2567,7 +2838,7 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
   const bool fold_big = lnfuse && fold_big_enabled && T > 4 * kSkinnyM && H % 64 == 0 && enc->layers[0].cs_1 != nullptr;
   // ... and with an f16 residual stream (EPI_RLS_*): the pre-LayerNorm rows live in xh only. VR_ENCODE_RES16=0: f32 rows
   static const bool res16_enabled = !(getenv("VR_ENCODE_RES16") && atoi(getenv("VR_ENCODE_RES16")) == 0);
-  const bool res16 = fold_big && res16_enabled && pp_usable(H, H) && pp_usable(H, I);
+  const bool res16 = fold_big && res16_enabled && direct_usable(H, H) && direct_usable(H, I);
   float2* part = reinterpret_cast<float2*>(enc->lnpart);
   const int segs = H / 64;
   const unsigned fin_blocks = static_cast<unsigned>((T + 255) / 256);
