@@ -47,7 +47,7 @@ def child(model, n_seq, out_path, reps):
     e = Engine(H)
     enc.load_encoder(e, enc.BertDesc(shape.layers, H, shape.heads, I, pooling=pooling, precision="f16"), state)
     rng = np.random.default_rng(1)
-    lens = rng.integers(96, 141, size=n_seq)
+    lens = rng.integers(int(os.environ.get('AB_MINLEN', 96)), int(os.environ.get('AB_MAXLEN', 140)) + 1, size=n_seq)
     ids = torch.from_numpy(rng.integers(0, shape.vocab, size=int(lens.sum())).astype(np.int32)).to(dev)
     off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
     out = torch.empty((n_seq, H), device=dev)

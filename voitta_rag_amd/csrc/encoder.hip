@@ -1132,6 +1132,19 @@ __device__ int g_gemm_diag = 0;
 
 constexpr int kWaveStatHalfs = 128 * 4;  // 128 float2 per wave (direct_epilogue's row statistics), in halfs
 
+// Output rows are written once and read by the NEXT kernel, long after they have left the caches: non-temporal stores
+// (they do not push the weight panels and activation rows the other tiles still need out of L2). Measured +2.7 % on the
+// GEMMs and +2 % on the attention kernel that runs between them (profiles/r02_gemm_experiments.md §5);
+// -DVR_GEMM_PLAIN_STORES builds the comparison.
+template <typename T>
+__device__ __forceinline__ void out_store(T* p, const T& v) {
+#ifdef VR_GEMM_PLAIN_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+
 template <int EPI, bool FULL>
 __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane,
                                                 const float* __restrict__ bias, const float* __restrict__ R,
@@ -1161,6 +1174,16 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
   // fragment pair p2 (features fbase + 32 p2 .. + 7) outside, the eight 16-token pieces inside: the column
   // vectors (bias, LayerNorm gain / shift or column sums) of one pair stay in registers, not those of all four
   // fragments (which, with the residual rows in flight, did not fit next to the 128 accumulators)
+  // kFold without residual rows (the QKV and FFN-up projections): the (mean, 1/sigma) of the wave's 128 rows are the
+  // only per-row loads — all eight pieces' worth up front, for both fragment pairs (fetched piece by piece, one piece
+  // ahead, each of the 16 pieces waited ~1 us for 8 bytes)
+  constexpr bool kStatUpfront = (EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU);
+  float2 st8[kStatUpfront ? 8 : 1] = {};
+  if (kStatUpfront) {
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc)
+      st8[pc] = FULL ? (ln_stat + (row0 + 16 * pc))[static_cast<uint32_t>(tok)] : ln_stat[min(row0 + 16 * pc + tok, M - 1)];
+  }
 #pragma unroll
   for (int p2 = 0; p2 < 2; ++p2) {
     const int c0 = fbase + 32 * p2;
@@ -1200,13 +1223,13 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
       }
       if (kResidLN || kFold) st = ln_stat[rr];
     };
-    if (kResidual || kFold) fetch_residual(0, r4[0], st2[0]);
+    if ((kResidual || kFold) && !kStatUpfront) fetch_residual(0, r4[0], st2[0]);
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
       const int grow = row0 + 16 * pc + tok;
-      if ((kResidual || kFold) && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
+      if ((kResidual || kFold) && !kStatUpfront && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
       const bool ok = FULL || (grow < M && col_ok);
-      const float2 st = st2[pc & 1];
+      const float2 st = kStatUpfront ? st8[pc] : st2[pc & 1];
       float v[2][4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1251,9 +1274,9 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
         if (VR_DIAG(32)) {
           if (h[0] == static_cast<half_t>(123.0f) && h[7] == static_cast<half_t>(77.0f)) Ch[0] = h[3];  // (keeps the arithmetic alive)
         } else if (FULL)
-          *reinterpret_cast<f16x8*>(upiece(Ch, pc, col0 + 32 * p2) + loff) = h;
+          out_store(reinterpret_cast<f16x8*>(upiece(Ch, pc, col0 + 32 * p2) + loff), h);
         else if (ok)
-          *reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow) * N + c0) = h;
+          out_store(reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow) * N + c0), h);
       }
       if (!kHalfOut && FULL) {  // f32 row
         *reinterpret_cast<float4*>(upiece(C, pc, col0 + 32 * p2) + loff) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
@@ -1549,23 +1572,17 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     }
 
     // waves 0-3 are a segment ahead: they wait here for waves 4-7's last MFMA segment, so that all eight waves
-    // run the epilogue TOGETHER (bracketed by barriers it would run once per half, one after the other)
+    // run the epilogue TOGETHER (one half after the other costs 13 %: each wave's epilogue is bound by the latency of
+    // its own loads, and the two waves of a SIMD hide each other's — profiles/r02_gemm_experiments.md §4)
     if (wm == 0) VR_PP_BARRIER();
-    // Epilogue, straight from the accumulators. The MFMAs ran with the WEIGHT fragment as the A operand, so
-    // acc[i][j][r] of lane (t = lane & 15, g = lane >> 4) is token row 16 i + t, feature 4 g + r of weight
-    // fragment j — four CONSECUTIVE features of one token — and the W image was staged with its rows permuted
-    // (see set_ptrs) so that fragments 2p and 2p + 1 hold features 32 p + 8 g + {0..3} and {4..7}: a lane owns 8
-    // consecutive features per fragment pair = one 16-byte f16 store (or two 16-byte f32 stores), 64 contiguous
-    // bytes per token and instruction across the four lane groups. No transpose through LDS (it cost 128
-    // ds_write_b32 + 32 ds_read_b128 per wave and tile, about half of the f16-output epilogue) and no LDS use at
-    // all, so the next tile's loads may land while this runs.
+    // Epilogue, straight from the accumulators (direct_epilogue).
     // W hi / A hi of the next tile's K-tile 0 may still be in flight: waited for HERE, before this wave's
     // stores queue up behind them (vmcnt retires in order: a counted wait in the next main loop would otherwise
     // wait for the stores too).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!VR_DIAG(2)) {
-    // (the branch-free form of the epilogues that also read residual rows needs ~30 registers more than this kernel
-    // has left beside its staging state; those keep the predicated form)
+    // (the branch-free form needs a few registers more than this kernel has left beside its staging state, and measured
+    // the same here: what bounds this epilogue is the write burst, not the wait placement — profiles/r02_gemm_experiments.md)
     constexpr bool kBranchFree = EPI != EPI_BIAS_RESIDUAL_LN && EPI != EPI_BIAS_RESIDUAL_LN_STATS && EPI != EPI_RLS_R32_O16 &&
                                  EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
     if (kBranchFree && bm + GBM <= M && bn + GBN <= N)  // block-uniform
@@ -1582,7 +1599,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     tile = next;
     bm = nbm;
     bn = nbn;
-    set_ptrs(bm, bn);  // (again: recomputed here, the eight staging pointers need not stay in registers across the epilogue)
     VR_PP_BARRIER();
     if (wm == 1) VR_PP_BARRIER();  // waves 4-7 fall one segment behind again
   }  // tiles
@@ -2575,6 +2591,194 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_kernel(const half_t* __
   }
 }
 
+// ---- attention, one block per (sequence, head) -------------------------------------------------------------
+//
+// attention_f16_kernel above stages 64 keys at a time, once per 64-query block: for the ~118-token chunks of the
+// indexing path that is four staging phases per (sequence, head), each with its global-load latency exposed and its
+// V tile transposed through LDS by hand — the kernel runs at half of what its 1.6 GB per launch cost at the HBM rate.
+// Here the block stages the sequence's K and V rows ONCE, all loads of up to 128 keys in flight together, V stays
+// row-major in LDS and its transposed MFMA operand comes out of ds_read_b64_tr_b16 (lane 4q + p of a 16-lane group
+// addresses row q, columns 4p..4p+3 of a 4 x 16 block; lane i receives column i); the four waves then walk the
+// sequence's 16-query tiles (wave w: tiles w, w + 4, ...) against keys already in LDS. Same arithmetic as
+// attention_f16_kernel (logits on the f16 MFMA, online softmax in the log2 domain over 64-key tiles, P as f16).
+// `q_limit`: only queries below it are computed (the last layer of a CLS-pooled model needs token 0 only).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_seq_kernel(const half_t* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                            int seq0, int tok_base, int H, float scale, int q_limit,
+                                                            int lds_keys, half_t* __restrict__ ctx_h) {
+  constexpr int LDK = DH;       // halfs per staged row: unpadded, 16-byte chunks XOR-swizzled by the row instead
+  constexpr int CH = DH / 8;    // 16-byte chunks per row
+  // chunk c of K row r sits at c ^ kswz(r): the 16 rows x one chunk of a ds_read_b128 fragment read then cover all 64
+  // banks once; chunk c of V row r at c ^ vswz(r): the 8 rows x 32 bytes of a transposed read (per 32-lane half) do
+  auto kswz = [](int r) { return DH == 64 ? (r >> 1) & 7 : (r >> 1) & 3; };
+  auto vswz = [](int r) { return DH == 64 ? ((r >> 1) & 3) << 1 : ((r >> 2) & 1) << 1; };
+  constexpr int NS = DH / 16;   // 16-wide d blocks of the output
+  constexpr int NKB = DH / 32;  // 32-deep MFMA steps over d
+  extern __shared__ __attribute__((aligned(16))) half_t att_lds[];
+  half_t* sK = att_lds;
+  half_t* sV = att_lds + static_cast<size_t>(lds_keys) * LDK;
+  // heads fastest: the twelve 128-byte slices of a token's Q/K/V row are then fetched by blocks that run side by side —
+  // one DRAM page opened once — instead of 2200 blocks apart (sequence-fastest order: 3.2 TB/s of 128-byte reads)
+  const int n_heads = H / DH;
+  const int seq = seq0 + static_cast<int>(blockIdx.x) / n_heads;
+  const int head = static_cast<int>(blockIdx.x) % n_heads;
+  const int t0 = cu[seq] - tok_base;
+  const int len = cu[seq + 1] - cu[seq];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 15, g = lane >> 4;
+  const int64_t row3 = 3 * static_cast<int64_t>(H);
+  // keys are staged and multiplied in groups of 16 (one MFMA tile): a 140-token sequence costs 9 groups, not 3 x 4
+  const int keys_pad = min((len + 15) & ~15, lds_keys);  // (len <= lds_keys: the host sizes the LDS by the longest sequence)
+
+  const int q_end = min(len, q_limit);
+  // Q rows go straight to registers; a wave's first tile is requested before the K/V loads, every further one while
+  // the tile before it is computed
+  auto load_q = [&](int qt, f16x8 (&q)[NKB]) {
+    const int tok = min(qt * 16 + qi, len - 1);
+    const half_t* qp = qkv + (t0 + tok) * row3 + head * DH + 8 * g;
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) q[u] = *reinterpret_cast<const f16x8*>(qp + 32 * u);
+  };
+  f16x8 qf[NKB];
+  if (wave * 16 < q_end) load_q(wave, qf);
+  // stage K and V rows 0 .. keys_pad - 1 (zeros behind the sequence's end), up to 128 keys' loads in flight at once
+  const int total = keys_pad * CH;
+  constexpr int NST = 5;  // 16-byte loads of K and of V per thread and round: 160 keys of 64 dims in one round
+  for (int base = 0; base < total; base += NST * 256) {
+    uint4 kv[NST], vv[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = base + i * 256 + tid;
+      const int key = idx / CH, c8 = idx % CH;
+      kv[i] = vv[i] = make_uint4(0, 0, 0, 0);
+      if (idx < total && key < len) {
+        const half_t* p = qkv + (t0 + key) * row3 + H + head * DH + c8 * 8;
+        kv[i] = *reinterpret_cast<const uint4*>(p);
+        vv[i] = *reinterpret_cast<const uint4*>(p + H);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = base + i * 256 + tid;
+      const int key = idx / CH, c8 = idx % CH;
+      if (idx < total) {
+        *reinterpret_cast<uint4*>(sK + key * LDK + (c8 ^ kswz(key)) * 8) = kv[i];
+        *reinterpret_cast<uint4*>(sV + key * LDK + (c8 ^ vswz(key)) * 8) = vv[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  const float scale2 = scale * 1.4426950408889634f;  // logits in the log2 domain: the softmax uses v_exp_f32 directly
+  // transposed V reads: lane 4q + p of its 16-lane group -> row (key) q, columns 4p .. 4p + 3 of the block
+  // (block rows are key0 + q with key0 a multiple of 4: the swizzle of the row depends on 4 g + q alone)
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int tr_row = tr_q * LDK, tr_sw = vswz(4 * g + tr_q), tr_in = 4 * (tr_p & 1);
+  const int k_sw = kswz(qi);  // rows kt + 16 t + qi
+  for (int qt = wave; qt * 16 < q_end; qt += 4) {  // wave-uniform: EXEC stays full (the transposed reads need it)
+    const int q_tok = qt * 16 + qi;
+    const bool q_valid = q_tok < len;
+    f16x8 qn[NKB];
+    const bool more = (qt + 4) * 16 < q_end;
+    if (more) load_q(qt + 4, qn);
+    f32x4 o[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -__builtin_inff();
+    float l = 0.0f;
+    for (int kt = 0; kt < keys_pad; kt += 64) {
+      const int nt = min(4, (keys_pad - kt) >> 4);  // 16-key groups in this tile (block-uniform)
+      f32x4 st[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < nt) {
+#pragma unroll
+          for (int u = 0; u < NKB; ++u) {
+            const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + (kt + t * 16 + qi) * LDK + ((4 * u + g) ^ k_sw) * 8);
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u], st[t], 0, 0, 0);
+          }
+        }
+      }
+      float mx = -__builtin_inff();
+      if (kt + 64 <= len) {  // every key of the tile exists: no masks
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] *= scale2;
+            mx = fmaxf(mx, st[t][r]);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt + t * 16 + 4 * g + r;
+            const float v = key < len ? st[t][r] * scale2 : -__builtin_inff();
+            st[t][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);  // finite: key kt < len is always valid
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float psum = 0.0f;
+      f16x8 pb[2];  // pb[u][j]: key kt + 32 u + 16 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[t][r] - m_new);
+          psum += p;
+          pb[t >> 1][(t & 1) * 4 + r] = static_cast<half_t>(p);
+        }
+      l = l * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) o[s] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          // V^T fragment: d = 16 s + qi, k index 8 g + j <-> the key of pb[u][j]: two 4-key blocks, 16 keys apart
+          // (a group behind the staged keys contributes nothing: its P values are zero, its V rows are not read)
+          if (2 * u >= nt) continue;
+          const half_t* vb = sV + (kt + 32 * u + 4 * g) * LDK + tr_row + ((2 * s + (tr_p >> 1)) ^ tr_sw) * 8 + tr_in;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+          s16x4 hi = s16x4{0, 0, 0, 0};
+          if (2 * u + 1 < nt) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 16 * LDK));
+          f16x8 vf;
+          *reinterpret_cast<s16x4*>(&vf) = lo;
+          *(reinterpret_cast<s16x4*>(&vf) + 1) = hi;
+          o[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u], o[s], 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (q_valid) {
+      const float inv = 1.0f / l;
+      const int64_t off = static_cast<int64_t>(t0 + q_tok) * H + head * DH + 4 * g;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        half_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = static_cast<half_t>(fminf(fmaxf(o[s][r] * inv, -65504.0f), 65504.0f));
+        *reinterpret_cast<uint2*>(ctx_h + off + 16 * s) = *reinterpret_cast<const uint2*>(h);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NKB; ++u) qf[u] = qn[u];
+    }
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 
 static int dev_alloc_copy(vr_engine* e, Encoder* enc, const void* src, size_t n_floats, int mem, float** out) {
@@ -2883,7 +3087,30 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
     const int qb = tail ? 1 : qblocks;  // tail: only the query block that holds token 0 of every sequence
     dim3 agrid(static_cast<unsigned>(n_seq * qb), static_cast<unsigned>(nh));
     prof_begin(e, VR_PROF_ATTENTION, tail ? attn_flop / qblocks : attn_flop);
-    if (plain && dh == 64)  // (8 waves = 128 queries per block stage K/V once per 128-token sequence, and measured 30 % slower)
+    static const bool attn_seq = !(getenv("VR_ATTN_SEQ") && atoi(getenv("VR_ATTN_SEQ")) == 0);
+    if (plain && attn_seq && (dh == 64 || dh == 32)) {  // one block per (sequence, head): K/V staged once
+      const int lds_keys = (max_len + 15) & ~15;
+      const size_t lds_bytes = static_cast<size_t>(2) * lds_keys * dh * sizeof(half_t);
+      static size_t lds_allowed[2] = {0, 0};  // per instantiation: raised above the 64 KiB default when a sequence needs it
+      const int which = dh == 64 ? 0 : 1;
+      if (lds_bytes > 65536 && lds_bytes > lds_allowed[which]) {
+        if (dh == 64)
+          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+        else
+          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+        lds_allowed[which] = lds_bytes;
+      }
+      const dim3 sgrid(static_cast<unsigned>(n_seq) * static_cast<unsigned>(nh));
+      const int q_limit = tail ? 16 : max_len;
+      if (dh == 64)
+        hipLaunchKernelGGL((attention_seq_kernel<64>), sgrid, dim3(256), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv),
+                           cu_dev, seq0, tok_base, H, scale, q_limit, lds_keys, ch);
+      else
+        hipLaunchKernelGGL((attention_seq_kernel<32>), sgrid, dim3(256), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv),
+                           cu_dev, seq0, tok_base, H, scale, q_limit, lds_keys, ch);
+    } else if (plain && dh == 64)  // (8 waves = 128 queries per block stage K/V once per 128-token sequence, and measured 30 % slower)
       hipLaunchKernelGGL((attention_f16_kernel<64, 4>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
                          cu_dev, seq0, tok_base, H, qb, scale, ch);
     else if (plain)
