@@ -1131,6 +1131,7 @@ __device__ int g_gemm_diag = 0;
 #endif
 
 constexpr int kWaveStatHalfs = 128 * 4;  // 128 float2 per wave (direct_epilogue's row statistics), in halfs
+constexpr int kTileConstHalfs = (3 * 256 * 4 + 256 * 8) / 2;  // a tile's bias / gain / shift vectors and row statistics
 
 // Output rows are written once and read by the NEXT kernel, long after they have left the caches: non-temporal stores
 // (they do not push the weight panels and activation rows the other tiles still need out of L2). Measured +2.7 % on the
@@ -1151,7 +1152,8 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
                                                 float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl,
                                                 int M, int N, float unscale, const float2* __restrict__ ln_stat,
                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                float2* wave_stat) {
+                                                float2* wave_stat, const float* tile_const = nullptr, int trow0 = 0,
+                                                int tcol0 = 0) {
   const int tok = lane & 15, fg = lane >> 4;
 #ifdef VR_GEMM_DIAG_BUILD
   const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
@@ -1177,9 +1179,14 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
   // kFold without residual rows (the QKV and FFN-up projections): the (mean, 1/sigma) of the wave's 128 rows are the
   // only per-row loads — all eight pieces' worth up front, for both fragment pairs (fetched piece by piece, one piece
   // ahead, each of the 16 pieces waited ~1 us for 8 bytes)
+  // tile_const (FULL tiles of gemm_f16_pp_kernel): the tile's 256 bias / gain / shift values and its 256 rows' statistics
+  // were fetched into LDS while the main loop ran — [bias 256][gain or column sums 256][shift 256][float2 stat 256];
+  // trow0 / tcol0 = this wave's first row / column inside the tile
+  const bool in_lds = FULL && tile_const != nullptr;
+  const float2* lds_stat = reinterpret_cast<const float2*>(tile_const + 768) + trow0;
   constexpr bool kStatUpfront = (EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU);
   float2 st8[kStatUpfront ? 8 : 1] = {};
-  if (kStatUpfront) {
+  if (kStatUpfront && !in_lds) {
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc)
       st8[pc] = FULL ? (ln_stat + (row0 + 16 * pc))[static_cast<uint32_t>(tok)] : ln_stat[min(row0 + 16 * pc + tok, M - 1)];
@@ -1194,6 +1201,13 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
     for (int q = 0; q < 2; ++q) {
       const uint32_t lc = static_cast<uint32_t>(8 * fg + 4 * q);
       const int uc = col0 + 32 * p2;
+      if (in_lds) {
+        const float* tc = tile_const + tcol0 + 32 * p2 + lc;
+        b4[q] = *reinterpret_cast<const float4*>(tc);
+        if (kResidLN || kFold) lg4[q] = *reinterpret_cast<const float4*>(tc + 256);
+        if (kResidLN) lb4[q] = *reinterpret_cast<const float4*>(tc + 512);
+        continue;
+      }
       b4[q] = FULL ? *reinterpret_cast<const float4*>(bias + uc + lc) : *reinterpret_cast<const float4*>(bias + cs + 4 * q);
       if (kResidLN || kFold)
         lg4[q] = FULL ? *reinterpret_cast<const float4*>(ln_g + uc + lc) : *reinterpret_cast<const float4*>(ln_g + cs + 4 * q);
@@ -1211,7 +1225,7 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
           r[0] = *reinterpret_cast<const float4*>(upiece(R, pc, col0 + 32 * p2) + loff);
           r[1] = *reinterpret_cast<const float4*>(upiece(R, pc, col0 + 32 * p2 + 4) + loff);
         }
-        if (kResidLN || kFold) st = (ln_stat + (row0 + 16 * pc))[static_cast<uint32_t>(tok)];
+        if (kResidLN || kFold) st = in_lds ? lds_stat[16 * pc + tok] : (ln_stat + (row0 + 16 * pc))[static_cast<uint32_t>(tok)];
         return;
       }
       const int64_t rr = min(row0 + 16 * pc + tok, M - 1);
@@ -1229,7 +1243,7 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
       const int grow = row0 + 16 * pc + tok;
       if ((kResidual || kFold) && !kStatUpfront && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
       const bool ok = FULL || (grow < M && col_ok);
-      const float2 st = kStatUpfront ? st8[pc] : st2[pc & 1];
+      const float2 st = kStatUpfront ? (in_lds ? lds_stat[16 * pc + tok] : st8[pc]) : st2[pc & 1];
       float v[2][4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1353,7 +1367,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
     int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
     const float* __restrict__ ln_b, int stagger_sleeps) {
-  __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
+  __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs + kTileConstHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
   const int tiles_n = (N + GBN - 1) / GBN;
   const int tiles_m = (M + GBM - 1) / GBM;
   const int total = tiles_m * tiles_n;
@@ -1377,6 +1391,26 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   float2* wave_stat = reinterpret_cast<float2*>(lds + 2 * kStageHalfs + wave * kWaveStatHalfs);
+  // the tile's epilogue constants (direct_epilogue: tile_const), fetched by waves 0-4 at the start of the tile's K loop —
+  // one direct-to-LDS load each — so that the epilogue starts on LDS reads instead of three rounds of global-load latency
+  half_t* tile_const_h = lds + 2 * kStageHalfs + 8 * kWaveStatHalfs;
+  constexpr bool kUsesGain = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU || EPI == EPI_BIAS_RESIDUAL_LN ||
+                             EPI == EPI_BIAS_RESIDUAL_LN_STATS || EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16 ||
+                             EPI == EPI_RLS_R16_O32;
+  constexpr bool kUsesShift = kUsesGain && EPI != EPI_FOLD_F16 && EPI != EPI_FOLD_GELU;
+  // (the branch-free form of the epilogues that also read residual rows needs ~30 registers more than this kernel
+  // has left beside its staging state; those keep the predicated form and their global loads)
+  constexpr bool kBranchFree = EPI != EPI_BIAS_RESIDUAL_LN && EPI != EPI_BIAS_RESIDUAL_LN_STATS && EPI != EPI_RLS_R32_O16 &&
+                               EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
+  auto issue_tile_consts = [&](int bm_, int bn_) {
+    if (!kBranchFree || bm_ + GBM > M || bn_ + GBN > N) return;  // edge tiles read them from global memory (predicated epilogue)
+    const int l8 = lane * 8;  // 16 bytes per lane, in halfs
+    if (wave == 0) glds16(reinterpret_cast<const half_t*>(bias + bn_) + l8, tile_const_h);
+    if (wave == 1 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_g + bn_) + l8, tile_const_h + 512);
+    if (wave == 2 && kUsesShift) glds16(reinterpret_cast<const half_t*>(ln_b + bn_) + l8, tile_const_h + 1024);
+    if (wave == 3 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_stat + bm_) + l8, tile_const_h + 1536);
+    if (wave == 4 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_stat + bm_ + 128) + l8, tile_const_h + 2048);
+  };
   // Phase diversity: every block's tile takes the same time, so without this all 256 CUs reach their
   // epilogues together — a burst of stores at the chip's store bandwidth with every matrix pipe idle,
   // followed by a main loop with the store path idle. Block `local` (of G) starts local / G of
@@ -1481,6 +1515,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       for (int j = 0; j < 2; ++j) bf[j][0] = bf[j][1] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
 #endif
       // ---- phase 0: quadrant rows 0-63 x columns 0-31 ------------------------------------------------
+      if (kt == 0) issue_tile_consts(bm, bn);  // (older than every load the counted waits below reason about)
       if (!VR_DIAG(1)) glds16(g_a0 + koff, nd + da0);
       if (!VR_DIAG(1)) glds16(g_a1 + koff, nd + da1);
 #pragma unroll
@@ -1581,12 +1616,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     // wait for the stores too).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!VR_DIAG(2)) {
-    // (the branch-free form needs a few registers more than this kernel has left beside its staging state, and measured
-    // the same here: what bounds this epilogue is the write burst, not the wait placement — profiles/r02_gemm_experiments.md)
-    constexpr bool kBranchFree = EPI != EPI_BIAS_RESIDUAL_LN && EPI != EPI_BIAS_RESIDUAL_LN_STATS && EPI != EPI_RLS_R32_O16 &&
-                                 EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
     if (kBranchFree && bm + GBM <= M && bn + GBN <= N)  // block-uniform
-      direct_epilogue<EPI, true>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
+      direct_epilogue<EPI, true>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
+                                 reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64);
     else
       direct_epilogue<EPI, false>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
     } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
