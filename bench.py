@@ -416,6 +416,7 @@ def main():
     dt = time.perf_counter() - t0
     gemm_ms, gemm_n, gemm_flop = engine.profile_read(Engine.PROF_GEMM)
     attn_ms, attn_n, attn_flop = engine.profile_read(Engine.PROF_ATTENTION)
+    attn_bytes = MODEL["layers"] * tokens * 4 * dim * 2.0  # per layer: Q, K, V read + context written, f16
     engine.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
@@ -638,8 +639,23 @@ def main():
                 "share_of_call_time": round(bscan_ms * 1e-3 / batch_dt, 4),
                 "traffic": pmc_traffic("batch_scan_kernel"),
             },
-            "attention": {"avg_launch_ms": round(attn_ms / max(attn_n, 1), 4),
-                          "TFLOPs": round(attn_flop / (attn_ms * 1e-3) / 1e12, 2) if attn_ms > 0 else None},
+            # attention reads Q, K, V once (f16) and writes the context rows: 4 H halfs per token and launch — at the
+            # ~118-token sequences of the indexing path it is bound by that traffic, not by its 1.1 TFLOP per batch
+            "roofline_attention": {
+                "kernel": "vr::attention_seq_kernel<64> (one block per (sequence, head): K/V rows staged once, "
+                          "v_mfma_f32_16x16x32_f16 for QK^T and PV, V^T fragments from ds_read_b64_tr_b16)",
+                "bound": "hbm",
+                "achieved": round(attn_bytes / (attn_ms * 1e-3) / 1e9, 1) if attn_ms > 0 else None,
+                "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s",
+                "frac": round(attn_bytes / (attn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if attn_ms > 0 else None,
+                "algorithmic_bytes_per_launch": round(attn_bytes / max(attn_n, 1)),
+                "launches": attn_n,
+                "avg_launch_ms": round(attn_ms / max(attn_n, 1), 4),
+                "TFLOPs": round(attn_flop / (attn_ms * 1e-3) / 1e12, 2) if attn_ms > 0 else None,
+                "share_of_step_time": round(attn_ms * 1e-3 / dt, 4),
+                "traffic": pmc_traffic("attention_seq_kernel"),
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, np.random.default_rng(3))
