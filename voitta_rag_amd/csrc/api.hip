@@ -188,6 +188,9 @@ static void lane_view(vr_engine* L, const vr_engine* m) {
   L->corpus16 = m->corpus16;
   L->row_scale = m->row_scale;
   L->row_err = m->row_err;
+  L->centre = m->centre;
+  L->centre_norm = m->centre_norm;
+  L->centre_rows = m->centre_rows;
   L->live = m->live;
   L->folder = m->folder;
   L->index_folder = m->index_folder;
@@ -368,6 +371,8 @@ void vr_engine_destroy(vr_engine* e) {
   e->corpus16.release();
   e->row_err.release();
   e->row_scale.release();
+  e->centre.release();
+  e->centre_sum.release();
   for (vr_engine* L : e->lanes_all) {
     if (L->own_stream) (void)hipStreamSynchronize(L->own_stream);
     release_scratch(L);
@@ -450,7 +455,14 @@ static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, c
     x_dev = e->stage_dense.p;
   }
   VR_TRY(dense_store_rows(e, x_dev, n, first));
-  VR_TRY(prefilter_store_rows(e, n, first));  // f16 shadow of the rows just stored (no-op without prefilter)
+  // shadow of the rows just stored (no-op without prefilter); the int8 shadow is re-centred — all of it rebuilt —
+  // whenever the collection has doubled since its centre was last computed
+  e->n_rows = first + n;  // (prefilter_recentre works on [0, n_rows); the count is set again below)
+  if (e->prefilter8 && first + n >= 1024 && first + n >= 2 * e->centre_rows)
+    VR_TRY(prefilter_recentre(e));
+  else
+    VR_TRY(prefilter_store_rows(e, n, first));
+  e->n_rows = first;
 
   // payload columns are always host arrays (they come from Python metadata)
   if (folder_id) {

@@ -50,7 +50,8 @@ constexpr int kQParams = 8;       // floats per query: a, b, |q|, |rho|, c_fixed
 // one block per query. Writes q^ (natural order), the two int8 images and the constants.
 __global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict__ q, int nq, int dim, int kb8n,
                                                          float* __restrict__ qhat, int8_t* __restrict__ img_a,
-                                                         int8_t* __restrict__ img_b, float* __restrict__ params) {
+                                                         int8_t* __restrict__ img_b, float* __restrict__ params,
+                                                         float centre_norm) {
   extern __shared__ __align__(16) float row[];  // [dim]
   __shared__ float red[3][4];
   __shared__ float len_s;
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict
     const float rho2_all = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
     const float qn = sqrtf(qn2) * 1.0001f + 1.0e-12f;
     const float rho_n = q_ok ? sqrtf(rho2_all) * 1.001f + 3.0e-7f * qn + 1.0e-12f : __builtin_inff();
-    const float c_fixed = static_cast<float>(dim) * 5.0e-7f * fmaxf(qn, 1.0f) + 1.0e-7f * qn * sqrtf(static_cast<float>(dim));
+    const float c_fixed = static_cast<float>(dim) * 5.0e-7f * fmaxf(qn, 1.0f) + 1.0e-7f * qn * sqrtf(static_cast<float>(dim)) +
+                          centre_norm * rho_n;  // (the centred shadow's |centre| |rho| term, as in prefilter_scan8_kernel)
     float* p = params + static_cast<int64_t>(qi) * kQParams;
     p[0] = a;
     p[1] = b;
@@ -401,7 +403,8 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   VR_HIP(hipMemsetAsync(e->bq_img.p, 0, static_cast<size_t>(2 * nq_pad * dim), s));  // padding queries: zeros
   VR_HIP(hipMemsetAsync(e->bq_cnt.p, 0, sizeof(int32_t) * 2 * static_cast<size_t>(nq), s));
   hipLaunchKernelGGL(batch_prep_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), static_cast<size_t>(dim) * sizeof(float),
-                     s, q_dev, nq, dim, kb8n, e->bq_hat.p, img_a, img_b, e->bq_params.p);
+                     s, q_dev, nq, dim, kb8n, e->bq_hat.p, img_a, img_b, e->bq_params.p,
+                     e->centre_rows > 0 ? e->centre_norm : 0.0f);
   const unsigned grid = static_cast<unsigned>(((n_rb + 7) / 8) * n_qc * 8);
   // algorithmic work of the batched scan: 2 N D Q operations (the second pass and the second query part are overhead)
   prof_begin(e, VR_PROF_BATCH_SCAN, 2.0 * static_cast<double>(e->n_rows) * dim * nq);

@@ -129,6 +129,8 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     t.corpus16.release();
     t.row_err.release();
     t.row_scale.release();
+    t.centre.release();
+    t.centre_sum.release();
     t.live.release();
     t.folder.release();
     t.index_folder.release();
@@ -198,7 +200,7 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     hipLaunchKernelGGL(restore_no_sparse_kernel, dim3(static_cast<unsigned>((n_new + 255) / 256)), dim3(256), 0, s,
                        has_sparse.p, n_new, t.row_slice.p);
   }
-  VR_CTRY(prefilter_store_rows(&t, n_new, 0));
+  VR_CTRY(prefilter_recentre(&t));  // the shadow of the compacted rows, around THEIR column mean
   VR_HIP(hipStreamSynchronize(s));
   VR_HIP(hipGetLastError());
 #undef VR_CTRY
@@ -209,6 +211,9 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     std::swap(e->corpus16, t.corpus16);
     std::swap(e->row_err, t.row_err);
     std::swap(e->row_scale, t.row_scale);
+    std::swap(e->centre, t.centre);
+    std::swap(e->centre_norm, t.centre_norm);
+    std::swap(e->centre_rows, t.centre_rows);
     std::swap(e->live, t.live);
     std::swap(e->folder, t.folder);
     std::swap(e->index_folder, t.index_folder);

@@ -160,6 +160,15 @@ struct vr_engine {
   // row_err the exact residual |x - scale * int8(x)|_2. Half the bytes of the f16 shadow again.
   bool prefilter8 = false;
   vr::DevArray<float> row_scale;
+  // Centre of the int8 shadow (prefilter.hip "centred shadow"): the shadow holds the quantised RESIDUALS x - centre.
+  // Any fixed vector is valid (a shift of every score by centre.q cancels out of the candidate test); the column
+  // mean of the stored rows makes the residuals of a real embedding collection — rows that share a common direction —
+  // several times smaller than the rows, and the bound with them. Recomputed (and the whole shadow rebuilt, ~1 ms per
+  // million rows) whenever the collection has doubled since the last time, after a compaction and after a load.
+  vr::DevArray<float> centre;      // [dim], zeros until the collection holds kCentreMinRows rows
+  vr::DevArray<float> centre_sum;  // [dim] scratch of the column sums
+  float centre_norm = 0.0f;        // |centre|_2, rounded up
+  int64_t centre_rows = 0;         // rows the collection held when the centre was last recomputed
   // (a lane counts for itself; its counts are added to the master's when it is handed back)
   std::atomic<int64_t> stat_two_stage{0};       // single-query dense searches served by the two-stage path
   std::atomic<int64_t> stat_fallback{0};        // ... of which overflowed the re-score budget and were redone one-stage
@@ -280,6 +289,8 @@ int dense_read_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, float* out
 
 // ---- prefilter.hip: f16 prefilter + exact re-score (two-stage exact search)
 int prefilter_store_rows(vr_engine* e, int64_t n, int64_t first_row);
+// recompute the centre of the int8 shadow from rows [0, n_rows) and rebuild the shadow of all of them
+int prefilter_recentre(vr_engine* e);
 bool prefilter_usable(vr_engine* e, int nq, int k);
 int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev, int32_t* out_count_dev);
 

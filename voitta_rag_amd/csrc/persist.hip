@@ -250,7 +250,8 @@ int engine_load(vr_engine* e, const char* path) {
   e->n_live = h.n_live;
   e->max_folder_id = h.max_folder_id;
   e->max_index_folder_id = h.max_index_folder_id;
-  VR_TRY(prefilter_store_rows(e, h.n_rows, 0));  // derived data: rebuilt, not stored
+  e->centre_rows = 0;
+  VR_TRY(prefilter_recentre(e));  // derived data (shadow and its centre): rebuilt, not stored
   VR_HIP(hipStreamSynchronize(e->stream));
   return 0;
 }

@@ -31,10 +31,22 @@
 //   error element-wise, growing linearly with D: ~4000 candidates. The row norm of the residual is what
 //   makes it usable.)
 
+// Centred shadow (int8 form): the shadow quantises r = x - c for one fixed vector c per engine (vr_engine::centre).
+//   x.q = c.q + r.q: the first term is the same real number for every row, so it drops out of "upper bound of row i
+//   >= k-th largest lower bound" — the scan works on r.q alone and never computes c.q. Only two things change:
+//   err_r = |r - s_r r8|_2 (plus 2^-23 (|x| + |c|) for the rounding of x - c), and |r| <= |x| + |c| in the
+//   (|r| + err_r) |rho| term, which the kernels take as |c| |rho| on top of their per-query constant. With c = 0 this
+//   is the uncentred scheme. c = column mean of the stored rows: on a collection whose rows share a common
+//   direction (pairwise cosine 0.7, as sentence embeddings do) the residuals are ~0.55 of the rows, candidates per
+//   query fall from ~6400 to a few hundred, and the batched search stops overflowing its per-query budget
+//   (scripts/perf_aniso.py).
+
 #include "engine_internal.h"
 #include "topk_device.h"
 
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 namespace vr {
 
@@ -82,16 +94,18 @@ __global__ __launch_bounds__(256) void shadow_rows8_kernel(const float* __restri
                                                            int64_t n, int dim, int kblocks,
                                                            int8_t* __restrict__ corpus8,
                                                            float* __restrict__ row_scale,
-                                                           float* __restrict__ row_err) {
+                                                           float* __restrict__ row_err,
+                                                           const float* __restrict__ centre, float centre_norm) {
   const int lane = threadIdx.x & 63;
   const int64_t row = first_row + static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= first_row + n) return;
   const int64_t tile = row / kTileRows;
   const int r = static_cast<int>(row % kTileRows);
   const int kb8n = dim / kK8;
-  auto at = [&](int k) {
+  auto at = [&](int k) {  // the residual x - centre (the row itself while there is no centre yet)
     const int kb = k / kTileK, kk = k % kTileK;
-    return corpus[((tile * kblocks + kb) * 64 + (kk % 4) * 16 + r) * 4 + kk / 4];
+    const float x = corpus[((tile * kblocks + kb) * 64 + (kk % 4) * 16 + r) * 4 + kk / 4];
+    return centre ? x - centre[k] : x;
   };
   float mx = 0.0f;
   for (int k = lane; k < dim; k += 64) mx = fmaxf(mx, fabsf(at(k)));
@@ -114,7 +128,9 @@ __global__ __launch_bounds__(256) void shadow_rows8_kernel(const float* __restri
     row_scale[row] = s;
     // rounded up: 0.1 % on the norm for the f32 summation, 2^-22 |x|_2 (<= mx sqrt(D)) for the
     // roundings inside d = x - s t, and an absolute floor
-    row_err[row] = finite ? sqrtf(e2) * 1.001f + 2.4e-7f * mx * sqrtf(static_cast<float>(dim)) + 1.0e-12f
+    // ... and 2^-23 (|x|_2 + |centre|_2) for the rounding of x - centre itself (|x|_2 <= 1.001: cosine-preprocessed)
+    row_err[row] = finite ? sqrtf(e2) * 1.001f + 2.4e-7f * mx * sqrtf(static_cast<float>(dim)) + 1.0e-12f +
+                                (centre ? 1.2e-7f * (1.001f + centre_norm) : 0.0f)
                           : __builtin_inff();
   }
 }
@@ -124,13 +140,75 @@ int prefilter_store_rows(vr_engine* e, int64_t n, int64_t first_row) {
   if (e->prefilter8)
     hipLaunchKernelGGL(shadow_rows8_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, e->stream,
                        e->corpus.p, first_row, n, e->dim, e->kblocks, reinterpret_cast<int8_t*>(e->corpus16.p),
-                       e->row_scale.p, e->row_err.p);
+                       e->row_scale.p, e->row_err.p, e->centre_rows > 0 ? e->centre.p : static_cast<const float*>(nullptr),
+                       e->centre_norm);
   else
     hipLaunchKernelGGL(shadow_rows_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, e->stream,
                        e->corpus.p, first_row, n, e->dim, e->kblocks, reinterpret_cast<half_t*>(e->corpus16.p),
                        e->row_err.p);
   VR_HIP(hipGetLastError());
   return 0;
+}
+
+// column sums of rows [0, n_rows) of the tiled f32 corpus: one block per 64 tiles, one thread per position of a tile's
+// k-block image, atomics into sum[dim] (a few thousand blocks x dim x 16 adds: microseconds)
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ corpus, int64_t n_rows, int kblocks,
+                                                         float* __restrict__ sum) {
+  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  for (int p = threadIdx.x; p < kblocks * 256; p += 256) {
+    const int kb = p >> 8, lane = (p >> 2) & 63, c = p & 3;
+    const int r = lane & 15;
+    float acc = 0.0f;
+    for (int64_t t = tile0; t < min(tile0 + 64, n_tiles); ++t)
+      if (t * kTileRows + r < n_rows) acc += corpus[(t * kblocks + kb) * 256 + p - (kb << 8)];
+    atomicAdd(sum + kb * kTileK + (lane >> 4) + 4 * c, acc);  // k = kTileK kb + (k % 4 = lane / 16) + 4 (k % 16 / 4 = c)
+  }
+}
+
+__global__ void centre_from_sum_kernel(const float* __restrict__ sum, int dim, float inv_n, float* __restrict__ centre) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < dim) centre[k] = sum[k] * inv_n;
+}
+
+constexpr int64_t kCentreMinRows = 1024;  // below this the shadow stays uncentred (centre = 0)
+
+int prefilter_recentre(vr_engine* e) {
+  if (!e->prefilter || !e->prefilter8 || e->n_rows <= 0) return 0;
+  const bool centring = !(getenv("VR_PREFILTER_CENTRE") && atoi(getenv("VR_PREFILTER_CENTRE")) == 0);  // (read per call: rare)
+  if (!centring) e->centre_rows = 0;
+  if (centring && e->n_rows >= kCentreMinRows) {
+    static_assert(kTileK == 16, "column_sum_kernel decodes the [k/16][lane][4] image");
+    VR_TRY(e->centre.grow(e->dim, 0, e->stream));
+    VR_TRY(e->centre_sum.grow(e->dim, 0, e->stream));
+    VR_HIP(hipMemsetAsync(e->centre_sum.p, 0, sizeof(float) * static_cast<size_t>(e->dim), e->stream));
+    const int64_t n_tiles = (e->n_rows + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(column_sum_kernel, dim3(static_cast<unsigned>((n_tiles + 63) / 64)), dim3(256), 0, e->stream,
+                       e->corpus.p, e->n_rows, e->kblocks, e->centre_sum.p);
+    hipLaunchKernelGGL(centre_from_sum_kernel, dim3(static_cast<unsigned>((e->dim + 255) / 256)), dim3(256), 0, e->stream,
+                       e->centre_sum.p, e->dim, 1.0f / static_cast<float>(e->n_rows), e->centre.p);
+    VR_HIP(hipGetLastError());
+    std::vector<float> host(static_cast<size_t>(e->dim));
+    VR_HIP(hipMemcpyAsync(host.data(), e->centre.p, sizeof(float) * host.size(), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    double n2 = 0.0;
+    bool finite = true;
+    for (float v : host) {
+      n2 += static_cast<double>(v) * v;
+      finite = finite && std::isfinite(v);
+    }
+    if (!centring) {
+      e->centre_norm = 0.0f;
+      e->centre_rows = 0;
+    } else if (finite) {
+      e->centre_norm = static_cast<float>(std::sqrt(n2) * 1.000001 + 1e-30);
+      e->centre_rows = e->n_rows;
+    } else {  // a row of infinities or NaNs was stored: no centre (its own bound is infinite either way)
+      e->centre_norm = 0.0f;
+      e->centre_rows = 0;
+    }
+  }
+  return prefilter_store_rows(e, e->n_rows, 0);
 }
 
 // ---- stage 1: query split + f16 scan -----------------------------------------------------------------
@@ -255,7 +333,7 @@ __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan_kernel(
 __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan8_kernel(
     const uint4* __restrict__ corpus8, const float* __restrict__ q_img, const float* __restrict__ row_err,
     const float* __restrict__ row_scale, const uint8_t* __restrict__ mask, int64_t n_tiles, int kb8n, int dim, int k,
-    float* __restrict__ upper, uint64_t* __restrict__ cand, int32_t* __restrict__ counter) {
+    float* __restrict__ upper, uint64_t* __restrict__ cand, int32_t* __restrict__ counter, float centre_norm) {
   extern __shared__ uint4 q_lds[];                                        // [2][kb8n][64] = 2*kb8n KiB
   __shared__ float red[3][kScan16Waves];
   uint64_t* lists = reinterpret_cast<uint64_t*>(q_lds + 2 * kb8n * 64);  // [waves][kListLen]
@@ -322,7 +400,9 @@ __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan8_kernel(
   // apart from the row's own terms: the exact f32 chain errs by at most ~2D roundings of 2^-24 relative to
   // sum |terms| <= 1.001 |q|; forming A = s (a dotA + b dotB) in f32 costs three roundings of its parts
   // (|b dotB s| <= |q| sqrt(D) / 254), charged per row below and here
-  const float c_fixed = static_cast<float>(dim) * 5.0e-7f * fmaxf(qn, 1.0f) + 1.0e-7f * qn * sqrtf(static_cast<float>(dim));
+  // (+ |centre| |rho|: the shadow holds residuals r = x - centre, |r| <= |x| + |centre| — see "Centred shadow" above)
+  const float c_fixed = static_cast<float>(dim) * 5.0e-7f * fmaxf(qn, 1.0f) + 1.0e-7f * qn * sqrtf(static_cast<float>(dim)) +
+                        centre_norm * rho_n;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint64_t* mine = lists + wave * kListLen;
@@ -541,7 +621,8 @@ int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out
     prof_begin(e, VR_PROF_DENSE_SCAN, static_cast<double>(e->n_rows) * (e->dim * 1.0 + 4.0 + 4.0 + 1.0 + 4.0));
     hipLaunchKernelGGL(prefilter_scan8_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kScan16Waves * 64), lds, s,
                        reinterpret_cast<const uint4*>(e->corpus16.p), e->q_tiled.p, e->row_err.p, e->row_scale.p,
-                       mask_dev, n_tiles, kb8n, e->dim, k, e->upper.p, e->cand_a.p, counter);
+                       mask_dev, n_tiles, kb8n, e->dim, k, e->upper.p, e->cand_a.p, counter,
+                       e->centre_rows > 0 ? e->centre_norm : 0.0f);
     prof_end(e);
   } else {
     const size_t lds = static_cast<size_t>(2) * kb16n * 1024 + kScan16Waves * kListLen * sizeof(uint64_t);
