@@ -57,6 +57,9 @@ def parse():
                         "11.9 of 12 rounds of the 256 CUs instead of 11.06 of 12 at 2048)")
     p.add_argument("--corpus", type=int, default=1_000_000, help="pre-populated rows per GPU")
     p.add_argument("--queries", type=int, default=1000)
+    p.add_argument("--aniso-rows", type=int, default=1_000_000,
+                   help="rows of the second, ANISOTROPIC corpus (common direction + noise, pairwise cosine 0.7) the dense search "
+                        "is also measured on (0 = skip; single GPU only)")
     p.add_argument("--dropin-files", type=int, default=2000,
                    help="synthetic documents pushed through the reference's unmodified per-file call sequence (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
@@ -271,6 +274,52 @@ def dropin_section(args, engine, state, rng):
         assert len(got) == 10
     store_registry.set_engine(None)  # (the engine stays ours to close)
     return n_chunks / dt, n_chunks, args.dropin_files, float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3)
+
+
+def anisotropic_section(args, torch, dev, dim):
+    """Dense top-10 on rows that share a common direction (pairwise cosine 0.7, what sentence-embedding collections
+    look like): scores sit three times closer together than on random unit rows while the int8 bound is as wide, which
+    is what the centred shadow (csrc/prefilter.hip) is for. Queries are drawn like the rows."""
+    from voitta_rag_amd import Engine
+
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    common = torch.nn.functional.normalize(torch.randn(dim, device=dev, generator=gen), dim=0)
+
+    def make(n):
+        u = torch.randn((n, dim), device=dev, generator=gen)
+        u = torch.nn.functional.normalize(u - (u @ common)[:, None] * common[None, :], dim=1)
+        return torch.nn.functional.normalize((0.7 ** 0.5) * common[None, :] + (0.3 ** 0.5) * u, dim=1).contiguous()
+
+    e = Engine(dim, device=dev.index or 0, initial_rows=args.aniso_rows)
+    for a in range(0, args.aniso_rows, 100_000):
+        e.upsert(make(min(100_000, args.aniso_rows - a)))
+    qs = make(220).cpu().numpy()
+    for i in range(20):
+        e.search_dense(qs[i:i + 1], 10)
+    s0 = e.stats()
+    lat, cand = np.empty(200), np.empty(200)
+    for i in range(200):
+        t0 = time.perf_counter()
+        e.search_dense(qs[20 + i:21 + i], 10)
+        lat[i] = time.perf_counter() - t0
+        cand[i] = e.stats()["last_candidates"]
+    s1 = e.stats()
+    qb = make(args.queries).cpu().numpy()
+    e.search_dense(qb, 10)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        e.search_dense(qb, 10)
+    dt = (time.perf_counter() - t0) / 3
+    s2 = e.stats()
+    out = {"rows": args.aniso_rows, "pairwise_cosine": 0.7,
+           "p50_dense_top10_ms": round(float(np.percentile(lat, 50) * 1e3), 4),
+           "p99_dense_top10_ms": round(float(np.percentile(lat, 99) * 1e3), 4),
+           "candidates_median": int(np.median(cand)), "candidates_max": int(cand.max()),
+           "fallbacks": s1["fallback"] - s0["fallback"],
+           "qps_batched": round(args.queries / dt, 1), "batched_fallbacks": s2["batch_fallback"] - s1["batch_fallback"]}
+    e.close()
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(kernel_prefix: str):
@@ -522,6 +571,18 @@ def main():
     del corpus_chunks
     torch.cuda.empty_cache()
 
+    # ---- the same dense search on an anisotropic corpus of the same size ---------------------------------------
+    aniso = None
+    if world == 1 and args.aniso_rows > 0:
+        # (isotropic reference for the same kind of query: dense top-10, query vector given)
+        iso_lat = np.empty(200)
+        for i in range(200):
+            t1 = time.perf_counter()
+            engine.search_dense(qs_host[20 + i: 21 + i], 10)
+            iso_lat[i] = time.perf_counter() - t1
+        aniso = anisotropic_section(args, torch, dev, dim)
+        aniso["isotropic_p50_dense_top10_ms"] = round(float(np.percentile(iso_lat, 50) * 1e3), 4)
+
     # ---- the reference's unmodified caller sequences on the native classes ---------
     dropin = None
     if world == 1 and args.dropin_files > 0:
@@ -577,6 +638,7 @@ def main():
                             "tests/test_fullsize_gpu.py)",
             "ms_per_batched_call": round(batch_dt / batch_reps * 1e3, 3),
             "recall_at_10_batched_vs_torch_matmul": recall_batched,
+            "anisotropic_corpus": aniso,
             "dropin_index_chunks_per_s": None if dropin is None else round(dropin[0], 1),
             "dropin_kind": None if dropin is None else
                 f"{dropin[2]} synthetic documents ({dropin[1]} chunks) from raw text through the reference's per-file sequence "

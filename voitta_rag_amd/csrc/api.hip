@@ -221,8 +221,15 @@ static vr_engine* lane_create(vr_engine* m) {
   L->kblocks = m->kblocks;
   L->prefilter = m->prefilter;
   L->prefilter8 = m->prefilter8;
+  // The auxiliary stream (the sparse leg of a hybrid search, forked beside the dense scan) gets the highest stream
+  // priority: streams of different priority never share a hardware queue. With equal priorities the runtime deals its
+  // 4 hardware queues round-robin over ALL streams of the process, the two streams of a lane could land on one queue,
+  // and the two legs then ran one after the other: hybrid p50 0.32 ms instead of 0.26 (scripts/perf_query_tail.py;
+  // GPU_MAX_HW_QUEUES=8 in the environment had the same effect, but a library cannot rely on its host's environment).
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
   bool ok = hipStreamCreateWithFlags(&L->own_stream, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&L->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithPriority(&L->aux_stream, hipStreamNonBlocking, prio_high) == hipSuccess &&
             hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&L->ev_input, hipEventDisableTiming) == hipSuccess &&
