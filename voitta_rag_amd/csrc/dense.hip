@@ -10,7 +10,7 @@
 // the A operand (A[i = l&15][k = l>>4]) of the c-th v_mfma_f32_16x16x4_f32 of that block, with k
 // increasing in natural order across c and kb. Because the f32 MFMA is bit-for-bit a k-ordered
 // fmaf chain, score(q, x) == fmaf(q[D-1], x[D-1], ... fmaf(q[0], x[0], 0.0f)) — the definition the
-// oracle restates (oracle/oracle_core.c).
+// oracle restates (the C restatement under oracle/, test infrastructure).
 //
 // Roofline: HBM. Algorithmic bytes per query pass = N * D * 4 (corpus) ; one pass serves up to
 // 16 queries (the MFMA N dimension), the MFMA pipe needs 1 KiB per 128 cycles per SIMD
