@@ -145,3 +145,43 @@ def test_batched_queries_equal_single_queries_at_full_size(corpus):
     blk = one.search_dense(qs[100:116], 10)
     for j in range(16):
         assert np.array_equal(batched[100 + j][0], blk[j][0]) and np.array_equal(batched[100 + j][1], blk[j][1])
+
+
+def test_configs4_shard_batched_equals_single_queries_1p25m_x_1024(gpu):
+    """BASELINE configs[4], one rank's share: a 1.25M x 1024 (bge-large width) shard of the 10M corpus, 1000 queries in
+    ONE call. The batched answers must equal 1000 single two-stage searches bit for bit — every one of them — and the
+    one-stage f32 scan on a sample; results sorted, ties by row. Rows share a common direction (real collections do),
+    so the centred shadow is what keeps the batch inside its candidate budget."""
+    import torch
+
+    from voitta_rag_amd import Engine
+
+    n, d = 1_250_000, 1024
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(44)
+    common = torch.nn.functional.normalize(torch.randn(d, device=dev, generator=g), dim=0)
+    two = Engine(d, initial_rows=n)
+    one = Engine(d, initial_rows=n, prefilter=False)
+    for a in range(0, n, 125_000):
+        x = torch.randn((125_000, d), device=dev, generator=g)
+        x = torch.nn.functional.normalize(x, dim=1) * (0.5 ** 0.5) + (0.5 ** 0.5) * common[None, :]   # pairwise cos ~0.5
+        x[:500] = x[0] + 0.02 * torch.randn((500, d), device=dev, generator=g)                          # a cluster per block
+        two.upsert(x.contiguous())
+        one.upsert(x.contiguous())
+    qs = torch.nn.functional.normalize(torch.randn((1000, d), device=dev, generator=g), dim=1) * (0.5 ** 0.5) + (0.5 ** 0.5) * common[None, :]
+    qs = qs.cpu().numpy()
+    before = two.stats()
+    batched = two.search_dense(qs, 10)
+    after = two.stats()
+    assert after["batched"] - before["batched"] == 1000
+    assert after["batch_fallback"] - before["batch_fallback"] < 50, after  # (a fallback is still exact; it must stay rare)
+    for i in range(1000):
+        r1, s1 = two.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+        assert np.all(s1[:-1] >= s1[1:]) and np.all(r1[:-1][s1[:-1] == s1[1:]] < r1[1:][s1[:-1] == s1[1:]])
+    assert two.stats()["fallback"] == before["fallback"]
+    for i in range(0, 1000, 50):
+        r1, s1 = one.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+    two.close()
+    one.close()
