@@ -8,7 +8,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_M
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
            ; do  # (a pass with TA_BUSY_avr / TA_*_STALLED_BY_TC_CYCLES_sum aborted rocprofv3 on this pool: left out)
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python $R/scripts/perf_encode.py bge-base-en-v1.5 256 128 2 f16 > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/p$i.log; }
+  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python $R/scripts/perf_encode.py bge-base-en-v1.5 ${PMC_SEQS:-2200} ${PMC_LEN:-0} 1 f16 > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/p$i.log; }
 done
 python - <<'PY'
 import csv, glob, collections
@@ -20,7 +20,7 @@ for f in glob.glob('/root/repo/gpurun_out/pmc_gemm/p*/**/*counter_collection.csv
         per[key] += float(r['Counter_Value']); names[r['Dispatch_Id']] = r['Kernel_Name']
     for (d, c), v in per.items():
         n = names[d]
-        k = 'gemm256<%s>' % n.split('ILi')[1][0] if 'gemm_f16x3_256' in n else ('attention' if 'attention' in n else None)
+        k = ('gemm_pp<EPI %s>' % n.split('ILi')[1].split('E')[0]) if 'gemm_f16_pp' in n else ('attention_seq' if 'attention_seq' in n else None)
         if k:
             acc[k][c][0] += 1; acc[k][c][1] += v
 for k in sorted(acc):
