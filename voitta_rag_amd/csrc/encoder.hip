@@ -2636,8 +2636,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_kernel(const half_t* __
 // `q_limit`: only queries below it are computed (the last layer of a CLS-pooled model needs token 0 only).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int DH>
-__global__ __launch_bounds__(256) void attention_seq_kernel(const half_t* __restrict__ qkv, const int32_t* __restrict__ cu,
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const half_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                             int seq0, int tok_base, int H, float scale, int q_limit,
                                                             int lds_keys, half_t* __restrict__ ctx_h) {
   constexpr int LDK = DH;       // halfs per staged row: unpadded, 16-byte chunks XOR-swizzled by the row instead
@@ -2679,12 +2679,13 @@ __global__ __launch_bounds__(256) void attention_seq_kernel(const half_t* __rest
   if (wave * 16 < q_end) load_q(wave, qf);
   // stage K and V rows 0 .. keys_pad - 1 (zeros behind the sequence's end), up to 128 keys' loads in flight at once
   const int total = keys_pad * CH;
-  constexpr int NST = 5;  // 16-byte loads of K and of V per thread and round: 160 keys of 64 dims in one round
-  for (int base = 0; base < total; base += NST * 256) {
+  constexpr int NT = NW * 64;
+  constexpr int NST = 20 / NW;  // 16-byte loads of K and of V per thread and round: 160 keys of 64 dims in one round
+  for (int base = 0; base < total; base += NST * NT) {
     uint4 kv[NST], vv[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int idx = base + i * 256 + tid;
+      const int idx = base + i * NT + tid;
       const int key = idx / CH, c8 = idx % CH;
       kv[i] = vv[i] = make_uint4(0, 0, 0, 0);
       if (idx < total && key < len) {
@@ -2695,7 +2696,7 @@ __global__ __launch_bounds__(256) void attention_seq_kernel(const half_t* __rest
     }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int idx = base + i * 256 + tid;
+      const int idx = base + i * NT + tid;
       const int key = idx / CH, c8 = idx % CH;
       if (idx < total) {
         *reinterpret_cast<uint4*>(sK + key * LDK + (c8 ^ kswz(key)) * 8) = kv[i];
@@ -2711,12 +2712,12 @@ __global__ __launch_bounds__(256) void attention_seq_kernel(const half_t* __rest
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
   const int tr_row = tr_q * LDK, tr_sw = vswz(4 * g + tr_q), tr_in = 4 * (tr_p & 1);
   const int k_sw = kswz(qi);  // rows kt + 16 t + qi
-  for (int qt = wave; qt * 16 < q_end; qt += 4) {  // wave-uniform: EXEC stays full (the transposed reads need it)
+  for (int qt = wave; qt * 16 < q_end; qt += NW) {  // wave-uniform: EXEC stays full (the transposed reads need it)
     const int q_tok = qt * 16 + qi;
     const bool q_valid = q_tok < len;
     f16x8 qn[NKB];
-    const bool more = (qt + 4) * 16 < q_end;
-    if (more) load_q(qt + 4, qn);
+    const bool more = (qt + NW) * 16 < q_end;
+    if (more) load_q(qt + NW, qn);
     f32x4 o[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -3127,21 +3128,24 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
       const int which = dh == 64 ? 0 : 1;
       if (lds_bytes > 65536 && lds_bytes > lds_allowed[which]) {
         if (dh == 64)
-          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<64>),
+          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<64, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
         else
-          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<32>),
+          VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_seq_kernel<32, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
         lds_allowed[which] = lds_bytes;
       }
       const dim3 sgrid(static_cast<unsigned>(n_seq) * static_cast<unsigned>(nh));
       const int q_limit = tail ? 16 : max_len;
-      if (dh == 64)
-        hipLaunchKernelGGL((attention_seq_kernel<64>), sgrid, dim3(256), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv),
-                           cu_dev, seq0, tok_base, H, scale, q_limit, lds_keys, ch);
-      else
-        hipLaunchKernelGGL((attention_seq_kernel<32>), sgrid, dim3(256), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv),
-                           cu_dev, seq0, tok_base, H, scale, q_limit, lds_keys, ch);
+      static const int attn_waves = getenv("VR_ATTN_WAVES") ? atoi(getenv("VR_ATTN_WAVES")) : 4;  // (experiment switch: 4 or 8)
+#define VR_ATTN_SEQ(DHV, NWV)                                                                                                   \
+  hipLaunchKernelGGL((attention_seq_kernel<DHV, NWV>), sgrid, dim3(NWV * 64), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv), \
+                     cu_dev, seq0, tok_base, H, scale, q_limit, lds_keys, ch)
+      if (dh == 64 && attn_waves == 8) VR_ATTN_SEQ(64, 8);
+      else if (dh == 64) VR_ATTN_SEQ(64, 4);
+      else if (attn_waves == 8) VR_ATTN_SEQ(32, 8);
+      else VR_ATTN_SEQ(32, 4);
+#undef VR_ATTN_SEQ
     } else if (plain && dh == 64)  // (8 waves = 128 queries per block stage K/V once per 128-token sequence, and measured 30 % slower)
       hipLaunchKernelGGL((attention_f16_kernel<64, 4>), agrid, dim3(256), 0, s, reinterpret_cast<const half_t*>(enc->qkv),
                          cu_dev, seq0, tok_base, H, qb, scale, ch);
