@@ -108,6 +108,16 @@ class DeferredEmbeddings(list):
         return self.array().tolist()
 
 
+class QueryEmbedding(list):
+    """What ``embed_query`` returns: the plain ``list[float]`` of the reference (embedding.py:76-86), which also keeps
+    the f32 array it was made from — ``VectorStoreService.search`` hands that to the engine instead of converting 768
+    Python floats back (the two conversions were a tenth of a query's wall time)."""
+
+    def __init__(self, array: np.ndarray):
+        super().__init__(array.tolist())
+        self.array = np.ascontiguousarray(array, np.float32)
+
+
 class SparseRef:
     """Entry ``index`` of a DeferredSparse: behaves like the (indices, values) tuple it stands for."""
 

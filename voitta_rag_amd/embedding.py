@@ -208,7 +208,7 @@ class EmbeddingService:
     def embed_query(self, query: str) -> list[float]:
         if "e5" in self.model_name.lower():  # embedding.py:82-83
             query = f"query: {query}"
-        return self.model.encode(query, convert_to_numpy=True).tolist()
+        return _deferred.QueryEmbedding(self.model.encode(query, convert_to_numpy=True))
 
 
 _embedding_service: EmbeddingService | None = None

@@ -749,7 +749,12 @@ class VectorStoreService:
             return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
         self._drain(col)
-        q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
+        kept = getattr(query_embedding, "array", None) if isinstance(query_embedding, _deferred.QueryEmbedding) else None
+        if (kept is not None and len(query_embedding) == kept.size == self.dimension
+                and query_embedding[0] == float(kept[0]) and query_embedding[-1] == float(kept[-1])):  # (not edited since)
+            q = kept.reshape(self.dimension)  # (embed_query's own array; the list was not needed)
+        else:
+            q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
         hybrid = bool(sparse_query and self._has_sparse and sparse_query[0])
         for attempt in range(64):
             with col.lock:
