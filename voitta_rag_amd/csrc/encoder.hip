@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const half_t* __restrict__ Ah, const half_t* __restrict__ Wh, const float* __restrict__ bias,
     const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
     int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
-    const float* __restrict__ ln_b, int stagger_sleeps) {
+    const float* __restrict__ ln_b, int stagger_sleeps, int group_m) {
   __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs + kTileConstHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
   const int tiles_n = (N + GBN - 1) / GBN;
   const int tiles_m = (M + GBM - 1) / GBM;
@@ -1375,11 +1375,11 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int local = (G % 8 == 0) ? (static_cast<int>(blockIdx.x) % 8) * (G / 8) + static_cast<int>(blockIdx.x) / 8
                                  : static_cast<int>(blockIdx.x);
   auto coords = [&](int t, int& bm_, int& bn_) {
-    const int per_group = kGroupM256 * tiles_n;
+    const int per_group = group_m * tiles_n;
     const int group = t / per_group;
     const int within = t - group * per_group;
-    const int gm = min(kGroupM256, tiles_m - group * kGroupM256);
-    bm_ = (group * kGroupM256 + within % gm) * GBM;
+    const int gm = min(group_m, tiles_m - group * group_m);
+    bm_ = (group * group_m + within % gm) * GBM;
     bn_ = (within / gm) * GBN;
   };
   int tile = local;
@@ -2079,6 +2079,8 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
   // start-time spread of the persistent blocks, as a fraction of one tile's time (estimated: ~2400 cycles per
   // K-tile + ~12000 of epilogue, in units of 64 cycles); only when a block walks several tiles
   static const float stagger_frac = getenv("VR_GEMM_STAGGER") ? static_cast<float>(atof(getenv("VR_GEMM_STAGGER"))) : 0.0f;
+  // row panels per group of the tile walk (column index slow inside a group): experiment switch VR_GEMM_GROUPM
+  static const int group_m = getenv("VR_GEMM_GROUPM") ? std::max(1, atoi(getenv("VR_GEMM_GROUPM"))) : kGroupM256;
   const int tiles_total = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
   const int stagger = tiles_total >= 3 * grid ? static_cast<int>(stagger_frac * ((K / 64) * 2400.0f + 12000.0f) / 64.0f) : 0;
 #ifdef VR_GEMM_DIAG_BUILD
@@ -2091,7 +2093,7 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
 #endif
 #define VR_LAUNCH_PP(E)                                                                                        \
   hipLaunchKernelGGL((gemm_f16_pp_kernel<E>), dim3(grid), dim3(512), 0, s, Ah, Wh, bias, R, C, Ch, Cl, M, N, K, \
-                     unscale, ln_stat, ln_g, ln_b, stagger)
+                     unscale, ln_stat, ln_g, ln_b, stagger, group_m)
   switch (epi) {
     case EPI_BIAS: VR_LAUNCH_PP(EPI_BIAS); break;
     case EPI_BIAS_GELU: VR_LAUNCH_PP(EPI_BIAS_GELU); break;
