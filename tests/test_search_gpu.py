@@ -474,3 +474,47 @@ def test_two_stage_search_on_an_anisotropic_corpus(gpu, dim, n, monkeypatch):
     centred, plain = run(True), run(False)
     print(f"anisotropic {n}x{dim}: median candidates {centred:.0f} centred, {plain:.0f} uncentred")
     assert centred * 2.5 < plain
+
+
+def test_caller_supplied_sizes_the_reference_accepts(gpu):
+    """`limit` is an MCP tool argument (mcp_server.py:376,474) and the reference accepts any value; so
+    does this — 100 hybrid results (prefetch 300 per modality), 300 dense results, a sparse query of 400 distinct
+    stems — bit-exact against the oracle, and the engine's caps (k <= 1024, 1024 query terms) fail with a message."""
+    from voitta_rag_amd._lib import EngineError
+
+    dim, n = 128, 6000
+    rng = np.random.default_rng(77)
+    x = _corpus(rng, n, dim)
+    sp = _sparse_rows(rng, n)
+    e = _engine(dim)
+    e.upsert(x, sparse=sp)
+    xh = ocore.cosine_preprocess(x)
+    live = np.ones(n, bool)
+    q = rng.standard_normal(dim).astype(np.float32)
+    dsc = ocore.dense_scores(ocore.cosine_preprocess(q[None]), xh)[0]
+    # dense, 300 results
+    wr, ws = ocore.topk(dsc, 300, live.astype(np.uint8))
+    gr, gs = e.search_dense(q[None], 300)[0]
+    assert np.array_equal(gr, wr) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    # hybrid, 100 results = two top-300 lists
+    qi = (rng.choice(500, size=6, replace=False).astype(np.int32) * 7919 + 13)
+    qv = np.ones(6, np.float32)
+    ssc = ocore.sparse_scores(sp, qi, qv, live)
+    dr, ds = ocore.topk(dsc, 300, live.astype(np.uint8))
+    sr, ss = ocore.topk(ssc, 300, live.astype(np.uint8))
+    fused = ofus.hybrid_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())), 100, 0.1, "json")
+    rows, scores, fd = e.search_hybrid(q, qi, qv, 100, 0.1)
+    assert rows.tolist() == [r for r, _, _ in fused] and scores.tolist() == [s for _, s, _ in fused]
+    # a sparse query of 400 distinct stems (a long pasted question)
+    qi = (rng.choice(500, size=400, replace=False).astype(np.int32) * 7919 + 13)
+    qv = np.ones(400, np.float32)
+    ssc = ocore.sparse_scores(sp, qi, qv, live)
+    wr, ws = ocore.topk(ssc, 50, live.astype(np.uint8))
+    gr, gs = e.search_sparse(qi, qv, 50)
+    assert np.array_equal(gr, wr) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    # beyond the caps: a clear error, not a crash
+    with pytest.raises(EngineError):
+        e.search_dense(q[None], 1025)
+    with pytest.raises(EngineError):
+        e.search_hybrid(q, qi[:3], qv[:3], 342, 0.1)
+    e.close()
