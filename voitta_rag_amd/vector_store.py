@@ -93,6 +93,7 @@ class _Collection:
         self.flusher: threading.Thread | None = None
         self.stopped = False
         self.deferred_error: BaseException | None = None
+        self.recovering = False  # the flusher is taking the rows of a failed fused call back out of the host table
 
     def stop(self) -> None:
         """End the flusher thread; queued stores are dropped (the engine they were meant for is going away)."""
@@ -514,20 +515,26 @@ class VectorStoreService:
             while col.pending_rows > self._MAX_PENDING_ROWS and not col.stopped and col.deferred_error is None:
                 col.pending_cv.wait(0.05)
         with col.write_lock:
-            self._raise_deferred_error(col)
-            first = self._append_host_rows(col, ids, payloads)
-            with col.lock:
-                folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
-                ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
-            entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(),
-                         wp_ids=np.asarray(wp_ids, np.int32), wp_off=np.asarray(wp_off, np.int64),
-                         bm_ids=None if bm_off is None else np.asarray(bm_ids, np.int32),  # None: a dense-only store
-                         bm_off=None if bm_off is None else np.asarray(bm_off, np.int64),
-                         folder=folder, ifolder=ifolder, created=created, modified=modified)
+            # host rows and queue entry go in together under the queue's lock (order: write_lock, pending_cv, table
+            # lock): a failing flush takes back exactly the rows of the entries it finds queued, and a store that
+            # arrives while it does so waits
             with col.pending_cv:
+                while col.recovering:
+                    col.pending_cv.wait(0.05)
+                err, col.deferred_error = col.deferred_error, None
+                if err is not None:
+                    raise RuntimeError("an earlier store_chunks could not be completed by the engine; its rows were dropped") from err
                 if col.stopped:
-                    self._drop_host_rows(col, first, ids, payloads)
                     raise RuntimeError("the collection was closed")
+                first = self._append_host_rows(col, ids, payloads)
+                with col.lock:
+                    folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
+                    ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
+                entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(),
+                             wp_ids=np.asarray(wp_ids, np.int32), wp_off=np.asarray(wp_off, np.int64),
+                             bm_ids=None if bm_off is None else np.asarray(bm_ids, np.int32),  # None: a dense-only store
+                             bm_off=None if bm_off is None else np.asarray(bm_off, np.int64),
+                             folder=folder, ifolder=ifolder, created=created, modified=modified)
                 col.pending.append(entry)
                 col.pending_rows += n
                 if col.flusher is None or not col.flusher.is_alive():
@@ -557,9 +564,15 @@ class VectorStoreService:
                 with col.pending_cv:
                     later, col.pending, col.pending_rows = col.pending, [], 0
                     col.deferred_error = e
-                for b in reversed(batch + later):  # rows that did not reach the engine: taken back, newest first
-                    if not b.get("done"):
-                        cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
+                    col.recovering = True
+                try:
+                    for b in reversed(batch + later):  # rows that did not reach the engine: taken back, newest first
+                        if not b.get("done"):
+                            cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
+                finally:
+                    with col.pending_cv:
+                        col.recovering = False
+                        col.pending_cv.notify_all()
             finally:
                 with col.pending_cv:
                     col.flushing = False
