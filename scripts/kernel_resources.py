@@ -10,7 +10,7 @@ bad = 0
 with tempfile.TemporaryDirectory() as tmp:
     for f in src:
         base = os.path.splitext(os.path.basename(f))[0]
-        subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "--offload-arch=gfx950",
                         "-I" + os.path.join(root, "include"), "-c", os.path.abspath(f), "-o", base + ".o", "-save-temps"],
                        cwd=tmp, check=True, stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, base + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
