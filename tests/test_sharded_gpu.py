@@ -96,3 +96,53 @@ def test_two_ranks_with_real_engines_equal_one_oracle_store(gpu, monkeypatch):
         for i in range(8):  # round-robin sharding: global id == original row
             wr, ws = ocore.topk(sc[i], 10)
             assert first[i][0] == wr.tolist() and first[i][1] == ws.tolist()
+
+
+def _rccl_worker(rank, world, port, ret):
+    """world = 1 over the REAL nccl (= RCCL) backend: the device-resident code path of ShardedSearcher — engine keys
+    written into a device tensor, all_gather_into_tensor on it, the device-side merge — on the one GPU a box has."""
+    import torch
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from voitta_rag_amd import Engine
+        from voitta_rag_amd.sharded import ShardedSearcher
+
+        rng = np.random.default_rng(9)
+        n, dim = 20000, 128
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        sp = [((rng.choice(300, size=5, replace=False) * 7 + 1).astype(np.int32), rng.uniform(0.5, 2.0, size=5).astype(np.float32))
+              for _ in range(n)]
+        e = Engine(dim, initial_rows=n)
+        e.upsert(x, sparse=sp)
+        s = ShardedSearcher(e)
+        assert s.on_device  # nccl: the communication tensors live on the GPU
+        q = rng.standard_normal((40, dim)).astype(np.float32)
+        sq = [((rng.choice(300, size=3, replace=False) * 7 + 1).astype(np.int32), np.ones(3, np.float32)) for _ in range(40)]
+        batch_d = s.search_dense_batch(q, 10)
+        batch_h = s.search_hybrid_batch(q, sq, 5, 0.25)
+        ok = True
+        for i in range(40):
+            rows, scores = e.search_dense(q[i:i + 1], 10)[0]   # world = 1: global id == row
+            ok &= np.array_equal(batch_d[i][0], rows) and np.array_equal(batch_d[i][1].view(np.uint32), scores.view(np.uint32))
+            d1 = s.search_dense(q[i], 10)
+            ok &= np.array_equal(d1[0], rows) and np.array_equal(d1[1].view(np.uint32), scores.view(np.uint32))
+            hr, hs, hf = e.search_hybrid(q[i], sq[i][0], sq[i][1], 5, 0.25)
+            bh = batch_h[i]
+            ok &= np.array_equal(bh[0], hr) and np.array_equal(bh[1], hs)
+            h1 = s.search_hybrid(q[i], sq[i][0], sq[i][1], 5, 0.25)
+            ok &= np.array_equal(h1[0], hr) and np.array_equal(h1[1], hs)
+        ret["ok"] = bool(ok)
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_device_resident_merge_over_rccl_with_one_rank(gpu):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret.get("ok") is True
