@@ -240,6 +240,9 @@ def dropin_section(args, engine, state, rng):
     docs = synthetic_documents(rng, words, args.dropin_files + 40)
 
     def index_file(i, content):
+        fp_ = f"dir{i % 7}/f{i}.md"
+        vs.count_by_file(fp_)    # the skip check of every file (indexing.py:239)
+        vs.delete_by_file(fp_)   # "delete existing chunks BEFORE parsing", every file, new ones included (indexing.py:281-288)
         chunks = chunker.chunk_text(content)
         texts = [c.text for c in chunks]
         embeddings = emb.embed_texts(texts)

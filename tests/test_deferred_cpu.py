@@ -175,8 +175,12 @@ def test_delete_and_plain_store_wait_for_queued_rows(store):
     vs, engine = store.vs, store.engine
     engine.delay = 0.05
     for f in range(6):
+        # IndexingService deletes a file's chunks before indexing it, every file (indexing.py:281-288): a delete that
+        # finds nothing must not wait for the queue, or the write-behind could never batch across files
+        assert vs.count_by_file(f"f{f}.md") == 0 and vs.delete_by_file(f"f{f}.md") == 0
         emb, sp, metas, _ = store.file_of(f"f{f}.md", 10)
         vs.store_chunks([(f"{f}:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    assert sum(engine.batches) < 60  # (rows are still queued: the six deletes above did not drain them)
     assert vs.delete_by_file("f5.md") == 10  # its rows were still queued: drained first, then deleted in the engine
     assert engine.count() == (60, 50)
     emb, sp, metas, _ = store.file_of("g.md", 2)

@@ -435,8 +435,15 @@ class VectorStoreService:
         steps look again."""
         col = self._col
         with col.write_lock:
-            self._drain(col)  # the rows to delete may still be on their way into the engine
             with col.lock:
+                rows = [r for r in select(col) if col.payload[r] is not None]
+            if not rows:
+                # nothing to delete — the common case: IndexingService deletes a file's chunks before it indexes the file,
+                # every file, new ones included (indexing.py:281-288). Not waiting for queued rows here is what lets the
+                # write-behind batch across files.
+                return 0
+            self._drain(col)  # the rows to delete may still be on their way into the engine
+            with col.lock:   # (a failed flush takes rows back: select again)
                 rows = [r for r in select(col) if col.payload[r] is not None]
             if not rows:
                 return 0
