@@ -649,7 +649,8 @@ def main():
             "dropin_index_chunks_per_s": None if dropin is None else round(dropin[0], 1),
             "dropin_kind": None if dropin is None else
                 f"{dropin[2]} synthetic documents ({dropin[1]} chunks) from raw text through the reference's per-file sequence "
-                "chunk_text -> embed_texts -> sparse embed_texts -> zip -> store_chunks (indexing.py:513-563) on the drop-in "
+                "count_by_file -> delete_by_file -> chunk_text -> embed_texts -> sparse embed_texts -> zip -> store_chunks "
+                "(indexing.py:239,284,513-563) on the drop-in "
                 "classes, one thread, until every row is searchable (write-behind: voitta_rag_amd/deferred.py)",
             "p50_query_from_text_ms": None if dropin is None else round(dropin[3], 4),
             "p99_query_from_text_ms": None if dropin is None else round(dropin[4], 4),
