@@ -1214,9 +1214,11 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
       if (kResidLN)
         lb4[q] = FULL ? *reinterpret_cast<const float4*>(ln_b + uc + lc) : *reinterpret_cast<const float4*>(ln_b + cs + 4 * q);
     }
-    // residual rows (and row statistics) of a piece are requested one piece ahead
-    float4 r4[2][2] = {};
-    float2 st2[2] = {};
+    // residual rows (and row statistics) of a piece are requested TWO pieces ahead (one piece of arithmetic is ~600 cycles,
+    // a global load 1-2 thousand: one ahead left every piece waiting)
+    constexpr int kAhead = 2;
+    float4 r4[kAhead + 1][2] = {};
+    float2 st2[kAhead + 1] = {};
     auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
       if (FULL) {
         if (kResidual && kR16) {
@@ -1237,20 +1239,24 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
       }
       if (kResidLN || kFold) st = ln_stat[rr];
     };
-    if ((kResidual || kFold) && !kStatUpfront) fetch_residual(0, r4[0], st2[0]);
+    if ((kResidual || kFold) && !kStatUpfront) {
+#pragma unroll
+      for (int pc = 0; pc < kAhead; ++pc) fetch_residual(pc, r4[pc], st2[pc]);
+    }
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
       const int grow = row0 + 16 * pc + tok;
-      if ((kResidual || kFold) && !kStatUpfront && pc + 1 < 8) fetch_residual(pc + 1, r4[(pc + 1) & 1], st2[(pc + 1) & 1]);
+      if ((kResidual || kFold) && !kStatUpfront && pc + kAhead < 8)
+        fetch_residual(pc + kAhead, r4[(pc + kAhead) % (kAhead + 1)], st2[(pc + kAhead) % (kAhead + 1)]);
       const bool ok = FULL || (grow < M && col_ok);
-      const float2 st = kStatUpfront ? (in_lds ? lds_stat[16 * pc + tok] : st8[pc]) : st2[pc & 1];
+      const float2 st = kStatUpfront ? (in_lds ? lds_stat[16 * pc + tok] : st8[pc]) : st2[pc % (kAhead + 1)];
       float v[2][4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
         const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
         const float lb[4] = {lb4[q].x, lb4[q].y, lb4[q].z, lb4[q].w};
-        const float4 rq = r4[pc & 1][kR16 ? 0 : q];
+        const float4 rq = r4[pc % (kAhead + 1)][kR16 ? 0 : q];
         float rr4[4] = {rq.x, rq.y, rq.z, rq.w};
         if (kR16) {
           const f16x8 rh = *reinterpret_cast<const f16x8*>(&rq);
