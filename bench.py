@@ -698,7 +698,11 @@ def main():
                 "launches": scan_n,
                 "avg_launch_ms": round(scan_ms / max(scan_n, 1), 4),
                 "sparse_scan_avg_ms": round(sp_ms / max(sp_n, 1), 4),
-                "sparse_scan_GBps": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1) if sp_ms > 0 else None,
+                # null when the queries ran on the inverted index (csrc/invert.hip): it reads its terms' postings
+                # only, a number the host does not know; VR_SPARSE_INVERTED=0 brings back the all-ids scan
+                "sparse_scan_GBps": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1) if sp_ms > 0 and sp_bytes > 0 else None,
+                "sparse_scan_kind": "inverted index (postings of the query's terms)" if sp_bytes == 0 and sp_n > 0
+                else "forward SELL-64 scan",
             },
             "roofline_batched_search": {
                 "kernel": "vr::batch_scan_kernel<PASS> (v_mfma_i32_16x16x64_i8: int8 shadow corpus x int8 query parts, two passes: "

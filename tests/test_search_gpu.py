@@ -518,3 +518,79 @@ def test_caller_supplied_sizes_the_reference_accepts(gpu):
     with pytest.raises(EngineError):
         e.search_hybrid(q, qi[:3], qv[:3], 342, 0.1)
     e.close()
+
+
+def test_inverted_sparse_scan_equals_the_forward_scan(gpu, monkeypatch, tmp_path):
+    """csrc/invert.hip (postings by term, what a query of <= 32 terms reads) against csrc/sparse.hip (every stored id)
+    and the oracle: same rows, same f32 bits — across batches that cut segments at odd places, rows that list a term
+    twice, deletes, filters, compaction and a save/load (the inverted index is derived data, rebuilt there)."""
+    from voitta_rag_amd import SearchFilter
+
+    dim, n = 16, 9000
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    sp = _sparse_rows(rng, n, vocab=300, lo=0, hi=30)
+    folder = rng.integers(0, 5, size=n).astype(np.int32)
+    e = _engine(dim)
+    cuts = [0, 1, 65, 2048, 2049, 4700, 8999, n]  # segments of 2048 rows start afresh with every batch
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e.upsert(x[a:b], sparse=sp[a:b], folder_ids=folder[a:b])
+    live = np.ones(n, bool)
+
+    def check(engine, rows_sp, live_mask, folders, tag):
+        for trial in range(10):
+            m = int(rng.integers(1, 33)) if trial else 32
+            qi = (rng.choice(300, size=m, replace=False).astype(np.int32) * 7919 + 13)
+            qv = rng.uniform(0.5, 1.5, size=m).astype(np.float32)
+            want = ocore.sparse_scores(rows_sp, qi, qv, live_mask)
+            for flt, mask in ((None, live_mask), (SearchFilter(folder_filter=2), live_mask & (folders == 2))):
+                for k in (1, 10, 64):
+                    wr, ws = ocore.topk(want, k, mask.astype(np.uint8))
+                    monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+                    gr, gs = engine.search_sparse(qi, qv, k, flt)
+                    monkeypatch.setenv("VR_SPARSE_INVERTED", "0")
+                    fr, fs = engine.search_sparse(qi, qv, k, flt)
+                    assert np.array_equal(gr, wr) and np.array_equal(fr, wr), (tag, trial, k)
+                    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), (tag, trial, k)
+                    assert np.array_equal(fs.view(np.uint32), ws.view(np.uint32)), (tag, trial, k)
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+
+    check(e, sp, live, folder, "fresh")
+    dead = rng.choice(n, size=2500, replace=False)
+    e.delete_rows(dead)
+    live[dead] = False
+    check(e, sp, live, folder, "deleted")
+    path = str(tmp_path / "inv.vrx")
+    e.save(path)
+    e2 = _engine(dim)
+    e2.load(path)
+    check(e2, sp, live, folder, "loaded")
+    e2.close()
+    remap = e.compact()
+    keep = np.flatnonzero(remap >= 0)
+    assert np.array_equal(remap[keep], np.arange(keep.size))
+    sp_c = [sp[i] for i in keep]
+    check(e, sp_c, np.ones(keep.size, bool), folder[keep], "compacted")
+    more = _sparse_rows(rng, 100, vocab=300, lo=1, hi=30)
+    e.upsert(x[:100], sparse=more, folder_ids=folder[:100])  # appends go on after a compaction
+    check(e, sp_c + more, np.ones(keep.size + 100, bool), np.concatenate([folder[keep], folder[:100]]), "appended")
+    e.close()
+
+    # rows that list a term twice (caller-supplied vectors may; the oracle's statistics count such a term once, the
+    # engine's once per entry, so here the two scans are held against each other): both entries count, in row order
+    d = _engine(dim)
+    rows = _sparse_rows(rng, 300, vocab=40, lo=2, hi=12)
+    for r in range(0, 300, 3):
+        ids, vals = rows[r]
+        rows[r] = (np.concatenate([ids, ids[:2]]), np.concatenate([vals, np.array([1.375, 0.3], np.float32)]))
+    d.upsert(x[:300], sparse=rows)
+    for trial in range(8):
+        qi = (rng.choice(40, size=5, replace=False).astype(np.int32) * 7919 + 13)
+        qv = rng.uniform(0.5, 1.5, size=5).astype(np.float32)
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+        gr, gs = d.search_sparse(qi, qv, 64)
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "0")
+        fr, fs = d.search_sparse(qi, qv, 64)
+        assert len(gr) > 0 and np.array_equal(gr, fr) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32))
+    monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+    d.close()

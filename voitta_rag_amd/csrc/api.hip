@@ -205,6 +205,12 @@ static void lane_view(vr_engine* L, const vr_engine* m) {
   L->sp_val = m->sp_val;
   L->sp_used = m->sp_used;
   L->n_sparse_points = m->n_sparse_points;
+  L->inv_key = m->inv_key;
+  L->inv_val = m->inv_val;
+  L->inv_seg = m->inv_seg;
+  L->inv_used = m->inv_used;
+  L->n_inv_seg = m->n_inv_seg;
+  L->inv_slices = m->inv_slices;
   L->df_keys = m->df_keys;
   L->df_cnt = m->df_cnt;
   L->df_cap = m->df_cap;
@@ -396,6 +402,7 @@ void vr_engine_destroy(vr_engine* e) {
   e->slices.release();
   e->sp_idx.release();
   e->sp_val.release();
+  inv_release(e);
   e->df_keys.release();
   e->df_cnt.release();
   if (e->df_distinct) (void)hipFree(e->df_distinct);

@@ -140,6 +140,7 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     t.slices.release();
     t.sp_idx.release();
     t.sp_val.release();
+    inv_release(&t);
     t.stage_i32a.release();
     t.stage_i32b.release();
     return rc;
@@ -224,6 +225,12 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     std::swap(e->sp_idx, t.sp_idx);
     std::swap(e->sp_val, t.sp_val);
     e->slices_host.swap(t.slices_host);
+    std::swap(e->inv_key, t.inv_key);
+    std::swap(e->inv_val, t.inv_val);
+    std::swap(e->inv_seg, t.inv_seg);
+    std::swap(e->inv_used, t.inv_used);
+    std::swap(e->n_inv_seg, t.n_inv_seg);
+    std::swap(e->inv_slices, t.inv_slices);
     e->n_slices_dev = t.n_slices_dev;
     e->sp_used = t.sp_used;
     e->cap_rows = t.cap_rows;

@@ -84,6 +84,21 @@ struct SliceDesc {
   int32_t pad;
 };
 
+// One segment of the inverted sparse index (invert.hip): the postings of <= kInvSegRows consecutive rows, sorted
+// by (term, row). A posting is a 64-bit key — bits 0..10 the row inside the segment, bits 11..41 the term id,
+// bits 42.. the segment's number inside its build batch (what the sort groups by) — plus the f32 weight.
+struct InvSeg {
+  int64_t off;       // first posting (into inv_key / inv_val)
+  int32_t count;
+  int32_t row_base;
+  int32_t nrows;
+  int32_t pad;
+};
+constexpr int kInvRowBits = 11;
+constexpr int kInvSegRows = 1 << kInvRowBits;
+constexpr int kInvSubShift = 42;
+constexpr int kInvMaxTerms = 32;   // queries with more distinct terms take the forward (SELL) scan
+
 constexpr int kTileRows = 16;      // corpus rows per MFMA tile (v_mfma_f32_16x16x4_f32 M)
 constexpr int kTileK = 16;         // k elements per 1-KiB tile block
 constexpr int kTopkSeg = 4096;     // keys per block in the first select level
@@ -198,6 +213,18 @@ struct vr_engine {
   vr::DevArray<float> sp_val;
   int64_t sp_used = 0;
   int64_t n_sparse_points = 0;
+
+  // inverted twin of the SELL index (invert.hip), derived data: rebuilt by vr_load and vr_compact
+  vr::DevArray<uint64_t> inv_key;
+  vr::DevArray<float> inv_val;
+  vr::DevArray<vr::InvSeg> inv_seg;
+  int64_t inv_used = 0;      // postings
+  int64_t n_inv_seg = 0;
+  int64_t inv_slices = 0;    // slices the inverted index covers (== n_slices_dev when usable)
+  vr::DevArray<uint64_t> inv_tmp_key;   // build scratch
+  vr::DevArray<float> inv_tmp_val;
+  vr::DevArray<uint8_t> inv_tmp_sort;
+  unsigned long long* inv_counter = nullptr;
 
   // document-frequency table: open addressing, key -1 = empty
   vr::DevArray<int32_t> df_keys;
@@ -326,6 +353,14 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old_host, int64_t* n_rows_a
 int bm25_tf(vr_engine* e, const int64_t* tok_off_dev, const int32_t* tok_ids_dev, int64_t n_docs,
             int64_t n_tokens, double k, double b, double avg_len, int32_t* out_cnt_dev,
             int32_t* out_idx_dev, double* out_val64_dev, float* out_val32_dev);
+// inverted index: postings of slices [slice0, slice0 + n_new) (consecutive rows from first_row; nnz = their real
+// entries, or -1 to have the device count them), and the one-kernel query over it
+int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, int64_t n_rows, int64_t nnz);
+int inv_rebuild(vr_engine* e);
+void inv_release(vr_engine* e);
+bool inv_usable(const vr_engine* e, int nnz);
+int inv_scan_topk(vr_engine* e, const int32_t* q_idx_dev, const float* q_val_dev, int nnz, bool weights_given,
+                  float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev);
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
                   const uint8_t* mask_dev, bool weights_given);
 int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,

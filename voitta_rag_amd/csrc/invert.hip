@@ -1,0 +1,351 @@
+// Inverted twin of the SELL-64 sparse index: what a single sparse (or hybrid) query reads.
+//
+// The forward scan of sparse.hip touches every stored id of the collection (4 B each: 166 MB for a million BM25
+// rows), whatever the query asks; run beside the dense int8 scan of a hybrid query it also takes HBM bandwidth from
+// it. A query of a handful of terms only needs the postings of those terms. They are kept here, derived from the
+// SELL slices (never persisted: vr_load and vr_compact rebuild them), in a shape that keeps the result the same
+// BITS as the forward scan's (reference behaviour restated in oracle/: score = sum over shared terms, ascending
+// token id, every multiply and add rounded to f32; src/voitta/services/vector_store.py:647-656 is the call this
+// serves):
+//
+//   * rows are cut into SEGMENTS of <= 2048 consecutive rows; a segment holds its postings sorted by (term, row),
+//     as 64-bit keys (segment number | term id | row inside the segment) with the f32 weights beside them. A batch
+//     of an upsert becomes its own segments (one device radix sort per batch, rocPRIM), nothing is merged later;
+//   * the query is ONE kernel, a block per segment: the query's terms are located in the segment by 64-way
+//     searches (a wave per term), then taken in ascending term order — the postings of one term name distinct rows,
+//     so the block adds them to a per-row f32 accumulator in LDS without conflicts, a barrier between terms keeps
+//     the summation order of the forward scan — and finally the rows that were hit (and pass the filter mask) go
+//     through the same per-wave top-k lists as every fused scan; merge_lists_kernel finishes.
+//
+// Algorithmic bytes: 12 B per posting of the query's terms + one mask byte per hit row; at a million rows and
+// five Zipf-head terms ≈ 20 MB instead of 166 MB. Queries with more than kInvMaxTerms distinct terms, k > 64,
+// and the all-scores entry point keep the forward scan (its cost does not grow with the number of terms).
+
+#include "engine_internal.h"
+#include "sparse_device.h"
+#include "topk_device.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace vr {
+
+constexpr int kInvWaves = 4;
+constexpr int kInvGroup = 8;  // terms whose postings a block requests together
+constexpr uint64_t kInvTermMask = 0x7FFFFFFFull;
+
+__device__ __forceinline__ int32_t inv_term(uint64_t key) {
+  return static_cast<int32_t>((key >> kInvRowBits) & kInvTermMask);
+}
+
+// ---- build ------------------------------------------------------------------------------------
+
+// One wave per slice, lane = row. Real ids form a prefix of a row's column (padding is -1), so a lane counts its
+// entries, the wave reserves room for all of them with one atomic and every lane writes its run.
+__global__ __launch_bounds__(64) void inv_emit_kernel(const SliceDesc* __restrict__ slices, int64_t slice0,
+                                                      int64_t first_row, const int32_t* __restrict__ sidx,
+                                                      const float* __restrict__ sval, uint64_t* __restrict__ keys,
+                                                      float* __restrict__ vals, unsigned long long* counter) {
+  const SliceDesc d = slices[slice0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  int c = 0;
+  if (lane < d.nrows)
+    for (int j = 0; j < d.width; ++j)
+      c += sidx[d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3)] >= 0;
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(total));
+  base = (static_cast<unsigned long long>(__shfl(static_cast<unsigned>(base >> 32), 0)) << 32) |
+         __shfl(static_cast<unsigned>(base), 0);
+  int64_t pos = static_cast<int64_t>(base) + incl - c;
+  const int64_t rel = d.row_base + lane - first_row;
+  const uint64_t hi = (static_cast<uint64_t>(rel >> kInvRowBits) << kInvSubShift) |
+                      static_cast<uint64_t>(rel & (kInvSegRows - 1));
+  for (int j = 0; j < c; ++j) {
+    const int64_t src = d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3);
+    keys[pos] = hi | (static_cast<uint64_t>(static_cast<uint32_t>(sidx[src])) << kInvRowBits);
+    vals[pos] = sval[src];
+    ++pos;
+  }
+}
+
+__device__ __forceinline__ int64_t inv_lower_bound(const uint64_t* __restrict__ keys, int64_t n, uint64_t target) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// keys: the sorted postings of one build batch; segment j of the batch = the keys with bits 42.. == j
+__global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n_ent, int64_t base_off,
+                                    int64_t first_row, int64_t n_rows, int n_sub, InvSeg* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_sub) return;
+  const int64_t lo = inv_lower_bound(keys, n_ent, static_cast<uint64_t>(j) << kInvSubShift);
+  const int64_t hi = inv_lower_bound(keys, n_ent, static_cast<uint64_t>(j + 1) << kInvSubShift);
+  InvSeg s;
+  s.off = base_off + lo;
+  s.count = static_cast<int32_t>(hi - lo);
+  s.row_base = static_cast<int32_t>(first_row + static_cast<int64_t>(j) * kInvSegRows);
+  const int64_t left = n_rows - static_cast<int64_t>(j) * kInvSegRows;
+  s.nrows = static_cast<int32_t>(left < kInvSegRows ? left : kInvSegRows);
+  s.pad = 0;
+  out[j] = s;
+}
+
+void inv_release(vr_engine* e) {
+  e->inv_key.release();
+  e->inv_val.release();
+  e->inv_seg.release();
+  e->inv_tmp_key.release();
+  e->inv_tmp_val.release();
+  e->inv_tmp_sort.release();
+  if (e->inv_counter) (void)hipFree(e->inv_counter);
+  e->inv_counter = nullptr;
+  e->inv_used = 0;
+  e->n_inv_seg = 0;
+  e->inv_slices = 0;
+}
+
+int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, int64_t n_rows, int64_t nnz) {
+  if (n_new <= 0) return 0;
+  VR_CHECK(slice0 == e->inv_slices, "inverted index out of step with the slices (%lld vs %lld)",
+           static_cast<long long>(e->inv_slices), static_cast<long long>(slice0));
+  VR_CHECK(n_rows >= 1 && n_rows < (1ll << 31) && slice0 + n_new <= static_cast<int64_t>(e->slices_host.size()),
+           "bad inverted-index batch");
+  const SliceDesc& last = e->slices_host[static_cast<size_t>(slice0 + n_new - 1)];
+  const int64_t room = nnz < 0 ? e->sp_used  // rebuild from a file: no assumption about the order of the slices
+                               : last.off + static_cast<int64_t>(last.width) * 64 -
+                                     e->slices_host[static_cast<size_t>(slice0)].off;
+  const int64_t n_sub = (n_rows + kInvSegRows - 1) / kInvSegRows;
+  if (!e->inv_counter) VR_HIP(hipMalloc(reinterpret_cast<void**>(&e->inv_counter), sizeof(unsigned long long)));
+  VR_HIP(hipMemsetAsync(e->inv_counter, 0, sizeof(unsigned long long), e->stream));
+  VR_TRY(e->inv_tmp_key.grow(std::max<int64_t>(room, 1), 0, e->stream));
+  VR_TRY(e->inv_tmp_val.grow(std::max<int64_t>(room, 1), 0, e->stream));
+  hipLaunchKernelGGL(inv_emit_kernel, dim3(static_cast<unsigned>(n_new)), dim3(64), 0, e->stream, e->slices.p,
+                     slice0, first_row, e->sp_idx.p, e->sp_val.p, e->inv_tmp_key.p, e->inv_tmp_val.p,
+                     e->inv_counter);
+  VR_HIP(hipGetLastError());
+  if (nnz < 0) {  // rebuild: only the device knows how many entries are real
+    unsigned long long c = 0;
+    VR_HIP(hipMemcpyAsync(&c, e->inv_counter, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    nnz = static_cast<int64_t>(c);
+  }
+  VR_CHECK(nnz <= room, "inverted-index batch of %lld entries in %lld slots", static_cast<long long>(nnz),
+           static_cast<long long>(room));
+  VR_TRY(e->inv_key.grow(std::max<int64_t>(e->inv_used + nnz, 1), e->inv_used, e->stream));
+  VR_TRY(e->inv_val.grow(std::max<int64_t>(e->inv_used + nnz, 1), e->inv_used, e->stream));
+  VR_TRY(e->inv_seg.grow(e->n_inv_seg + n_sub, e->n_inv_seg, e->stream));
+  if (nnz > 0) {
+    int sub_bits = 1;
+    while ((1ll << sub_bits) < n_sub) ++sub_bits;
+    const unsigned end_bit = static_cast<unsigned>(kInvSubShift + sub_bits);
+    size_t tmp_bytes = 0;
+    VR_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, e->inv_tmp_key.p, e->inv_key.p + e->inv_used,
+                                     e->inv_tmp_val.p, e->inv_val.p + e->inv_used, static_cast<size_t>(nnz), 0u,
+                                     end_bit, e->stream));
+    VR_TRY(e->inv_tmp_sort.grow(static_cast<int64_t>(std::max<size_t>(tmp_bytes, 1)), 0, e->stream));
+    VR_HIP(rocprim::radix_sort_pairs(e->inv_tmp_sort.p, tmp_bytes, e->inv_tmp_key.p, e->inv_key.p + e->inv_used,
+                                     e->inv_tmp_val.p, e->inv_val.p + e->inv_used, static_cast<size_t>(nnz), 0u,
+                                     end_bit, e->stream));
+  }
+  hipLaunchKernelGGL(inv_segments_kernel, dim3(static_cast<unsigned>((n_sub + 255) / 256)), dim3(256), 0, e->stream,
+                     e->inv_key.p + e->inv_used, nnz, e->inv_used, first_row, n_rows, static_cast<int>(n_sub),
+                     e->inv_seg.p + e->n_inv_seg);
+  VR_HIP(hipGetLastError());
+  e->inv_used += nnz;
+  e->n_inv_seg += n_sub;
+  e->inv_slices = slice0 + n_new;
+  return 0;
+}
+
+int inv_rebuild(vr_engine* e) {
+  e->inv_used = 0;
+  e->n_inv_seg = 0;
+  e->inv_slices = 0;
+  const int64_t n = static_cast<int64_t>(e->slices_host.size());
+  if (n == 0) return 0;
+  int64_t first = e->slices_host.front().row_base, end = first;
+  for (const SliceDesc& d : e->slices_host) {
+    first = std::min<int64_t>(first, d.row_base);
+    end = std::max<int64_t>(end, static_cast<int64_t>(d.row_base) + d.nrows);
+  }
+  if (end == first) {
+    e->inv_slices = n;
+    return 0;
+  }
+  VR_TRY(inv_append(e, 0, n, first, end - first, -1));
+  // the build scratch of a whole collection is large; batches that follow are small
+  VR_HIP(hipStreamSynchronize(e->stream));
+  e->inv_tmp_key.release();
+  e->inv_tmp_val.release();
+  e->inv_tmp_sort.release();
+  return 0;
+}
+
+// ---- query ------------------------------------------------------------------------------------
+
+static bool inv_enabled() {
+  const char* v = std::getenv("VR_SPARSE_INVERTED");  // read per call: tests compare both scans in one process
+  return !(v && v[0] == '0');
+}
+
+bool inv_usable(const vr_engine* e, int nnz) {
+  return inv_enabled() && nnz >= 1 && nnz <= kInvMaxTerms && e->n_inv_seg > 0 && e->inv_slices == e->n_slices_dev;
+}
+
+// Lower bound of term t among the keys of a segment, found by the whole wave: 64 probes per step.
+__device__ __forceinline__ int inv_wave_lower_bound(const uint64_t* __restrict__ kp, int count, int32_t t, int lane) {
+  int lo = 0, hi = count;  // the answer lies in [lo, hi]
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) >> 6;
+    const int p = lo + lane * step;
+    const bool less = p < hi && inv_term(kp[p]) < t;
+    const int c = __popcll(__ballot(less));  // the probes are ascending: `less` holds for a prefix of the lanes
+    const int nlo = c ? lo + (c - 1) * step + 1 : lo;
+    const int nhi = c < 64 ? min(hi, lo + c * step) : hi;
+    lo = nlo;
+    hi = nhi;
+  }
+  const int p = lo + lane;
+  const bool less = p < hi && inv_term(kp[p]) < t;
+  return lo + __popcll(__ballot(less));
+}
+
+__global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
+    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
+    const int32_t* __restrict__ q_idx, const float* __restrict__ q_val, int nnz, int weights_given,
+    const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
+  __shared__ float score[kInvSegRows];
+  __shared__ uint8_t hit[kInvSegRows];
+  __shared__ int32_t t_id[kInvMaxTerms];
+  __shared__ float t_w[kInvMaxTerms];
+  __shared__ int32_t t_lo[kInvMaxTerms];
+  __shared__ uint64_t lists[kInvWaves * kListLen];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t* list = lists + wave * kListLen;
+  lists[threadIdx.x] = 0ull;  // blockDim.x == kInvWaves * kListLen
+  if (static_cast<int>(threadIdx.x) < nnz) {
+    const int32_t id = q_idx[threadIdx.x];
+    t_id[threadIdx.x] = id;
+    t_w[threadIdx.x] = sparse_query_weight(q_val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
+  }
+  __syncthreads();
+
+  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+    const InvSeg seg = segs[s];
+    if (seg.count == 0) continue;  // block-uniform
+    const uint64_t* kp = keys + seg.off;
+    const float* vp = vals + seg.off;
+    for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) {
+      score[r] = 0.0f;
+      hit[r] = 0;
+    }
+    for (int i = wave; i < nnz; i += kInvWaves) {
+      const int lb = inv_wave_lower_bound(kp, seg.count, t_id[i], lane);
+      if (lane == 0) t_lo[i] = lb;
+    }
+    __syncthreads();
+    // Ascending term id: the forward scan's summation order. The postings of kInvGroup terms are requested
+    // together (a thread takes posting t_lo + tid of each: all addresses are known), so the terms that follow cost
+    // LDS work only; a term with more than 256 postings in this segment, or a row that lists it twice, takes the
+    // general loop below.
+    for (int g0 = 0; g0 < nnz; g0 += kInvGroup) {
+      uint64_t key[kInvGroup], prv[kInvGroup];
+      float val[kInvGroup];
+#pragma unroll
+      for (int u = 0; u < kInvGroup; ++u) {
+        const int i = g0 + u;
+        const int p = (i < nnz ? t_lo[i] : 0) + static_cast<int>(threadIdx.x);
+        const int pc = (i < nnz && p < seg.count) ? p : 0;
+        key[u] = kp[pc];
+        val[u] = vp[pc];
+        prv[u] = pc ? kp[pc - 1] : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kInvGroup; ++u) {
+        const int i = g0 + u;
+        if (i >= nnz) break;  // block-uniform
+        const int32_t t = t_id[i];
+        const float w = t_w[i];
+        const int p0 = t_lo[i] + static_cast<int>(threadIdx.x);
+        const bool mine = p0 < seg.count && inv_term(key[u]) == t;
+        const bool general = mine && (prv[u] == key[u] || threadIdx.x == kInvWaves * 64 - 1);
+        if (!__syncthreads_or(general)) {  // (the barrier also orders this term after the one before)
+          if (mine) {
+            const int r = static_cast<int>(key[u] & (kInvSegRows - 1));
+            score[r] = __fadd_rn(score[r], __fmul_rn(w, val[u]));
+            hit[r] = 1;
+          }
+          continue;
+        }
+        for (int p = t_lo[i] + wave * 64 + lane;; p += kInvWaves * 64) {
+          bool in_run = false;
+          if (p < seg.count) {
+            const uint64_t k2 = kp[p];
+            in_run = inv_term(k2) == t;
+            // a row that lists a term twice (caller-supplied vectors may) has equal keys side by side, in the row's
+            // own order (the sort is stable): the first of the run adds them all, one after the other
+            if (in_run && !(p > 0 && kp[p - 1] == k2)) {
+              const int r = static_cast<int>(k2 & (kInvSegRows - 1));
+              float acc = score[r];
+              int q = p;
+              do {
+                acc = __fadd_rn(acc, __fmul_rn(w, vp[q]));
+                ++q;
+              } while (q < seg.count && kp[q] == k2);
+              score[r] = acc;
+              hit[r] = 1;
+            }
+          }
+          if (!__all(in_run)) break;  // a wave's chunks only move away from the term's run
+        }
+      }
+    }
+    __syncthreads();
+    for (int r0 = wave * 64; r0 < seg.nrows; r0 += kInvWaves * 64) {
+      const int r = r0 + lane;
+      const bool in = r < seg.nrows && hit[r];
+      const int64_t row = static_cast<int64_t>(seg.row_base) + r;
+      const bool ok = in && mask[row];
+      wave_offer(list, k, ok ? topk_make_key(score[r], row) : 0ull, 0, ok, lane);
+    }
+    __syncthreads();  // the next segment clears the accumulators
+  }
+  block_merge_lists(lists, kListLen, kInvWaves, wave, lane);
+  if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
+}
+
+int inv_scan_topk(vr_engine* e, const int32_t* q_idx_dev, const float* q_val_dev, int nnz, bool weights_given,
+                  float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev) {
+  VR_CHECK(nnz >= 1 && nnz <= kInvMaxTerms && k >= 1 && k <= kListLen, "bad inverted-scan shape");
+  const int blocks = static_cast<int>(std::min<int64_t>(e->n_inv_seg, kScanBlocks));
+  VR_TRY(e->sp_cand.grow(static_cast<int64_t>(blocks) * kListLen, 0, e->stream));
+  // work 0: the postings the query's terms own are counted nowhere on the host (the slot's time and launch count
+  // are what bench.py reads for this scan)
+  prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
+  hipLaunchKernelGGL(sparse_inv_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kInvWaves * 64), 0, e->stream,
+                     e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_idx_dev, q_val_dev,
+                     nnz, weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev, k,
+                     e->sp_cand.p);
+  prof_end(e);
+  VR_HIP(hipGetLastError());
+  return topk_merge_lists(e, e->sp_cand.p, blocks, 1, k, out_keys_dev);
+}
+
+}  // namespace vr

@@ -17,6 +17,7 @@
 // the table content does not depend on arrival order).
 
 #include "engine_internal.h"
+#include "sparse_device.h"
 #include "topk_device.h"
 
 #include <algorithm>
@@ -24,11 +25,6 @@
 namespace vr {
 
 // ---- document-frequency table ---------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t df_hash(int32_t id) {
-  uint32_t h = static_cast<uint32_t>(id) * 0x9E3779B1u;
-  return h ^ (h >> 15);
-}
 
 __device__ __forceinline__ void df_add(int32_t* keys, int32_t* cnt, int64_t cap, int32_t id,
                                        int32_t delta, int32_t* distinct) {
@@ -47,18 +43,6 @@ __device__ __forceinline__ void df_add(int32_t* keys, int32_t* cnt, int64_t cap,
     h = (h + 1) & (cap - 1);
   }
   atomicAdd(&cnt[h], delta);
-}
-
-__device__ __forceinline__ int32_t df_get(const int32_t* keys, const int32_t* cnt, int64_t cap,
-                                          int32_t id) {
-  uint64_t h = df_hash(id) & (cap - 1);
-  for (int64_t probe = 0; probe < cap; ++probe) {
-    int32_t cur = keys[h];
-    if (cur == id) return cnt[h];
-    if (cur == -1) return 0;
-    h = (h + 1) & (cap - 1);
-  }
-  return 0;
 }
 
 __global__ void df_init_kernel(int32_t* keys, int32_t* cnt, int64_t cap) {
@@ -234,7 +218,7 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
   e->sp_used = used;
   e->n_slices_dev = static_cast<int64_t>(e->slices_host.size());
   if (account) e->n_sparse_points += n;
-  return 0;
+  return inv_append(e, slice0, n_new, first_row, n, nnz);  // the same rows, by term (invert.hip)
 }
 
 // ---- query ------------------------------------------------------------------------------------
@@ -268,18 +252,7 @@ __global__ __launch_bounds__(kSparseWaves * 64) void sparse_scores_kernel(
   for (int i = threadIdx.x; i < kQHash; i += kSparseWaves * 64) hk[i] = -1;
   if (static_cast<int>(threadIdx.x) < nnz) {
     const int32_t id = q_idx[threadIdx.x];
-    float w = q_val[threadIdx.x];
-    if (!weights_given) {
-      const float df = static_cast<float>(df_cap ? df_get(df_keys, df_cnt, df_cap, id) : 0);
-      const float num = __fadd_rn(__fadd_rn(n_points, -df), 0.5f);
-      const float den = __fadd_rn(df, 0.5f);
-      const float arg = __fadd_rn(1.0f, __fdiv_rn(num, den));
-      // ln in f64, rounded once to f32. The empty asm hides that `a` is a widened float: otherwise
-      // LLVM shrinks (float)log((double)x) to logf(x), whose last bit differs from the host's.
-      double a = static_cast<double>(arg);
-      asm volatile("" : "+v"(a));
-      w = __fmul_rn(w, static_cast<float>(log(a)));
-    }
+    const float w = sparse_query_weight(q_val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
     t_id[threadIdx.x] = id;
     t_w[threadIdx.x] = w;
   }
@@ -359,6 +332,8 @@ static int sparse_run(vr_engine* e, const int32_t* q_idx_host, const float* q_va
   const int32_t* did = pin_dev<int32_t>(e, kPinSparseIds);
   const float* dval = pin_dev<float>(e, kPinSparseVals);
   const float n_points = static_cast<float>(e->n_sparse_points);
+  if (fused_k && inv_usable(e, nnz))  // a few terms: their postings only
+    return inv_scan_topk(e, did, dval, nnz, weights_given, n_points, mask_dev, fused_k, out_keys_dev);
   if (fused_k) {
     int64_t blocks = std::min<int64_t>((e->n_slices_dev + kSparseWaves - 1) / kSparseWaves, kScanBlocks);
     if (blocks < 1) blocks = 1;
