@@ -532,7 +532,7 @@ def test_inverted_sparse_scan_equals_the_forward_scan(gpu, monkeypatch, tmp_path
     sp = _sparse_rows(rng, n, vocab=300, lo=0, hi=30)
     folder = rng.integers(0, 5, size=n).astype(np.int32)
     e = _engine(dim)
-    cuts = [0, 1, 65, 2048, 2049, 4700, 8999, n]  # segments of 2048 rows start afresh with every batch
+    cuts = [0, 1, 65, 2048, 2049, 4700, 8999, n]  # segments (<= 4096 rows) start afresh with every batch
     for a, b in zip(cuts[:-1], cuts[1:]):
         e.upsert(x[a:b], sparse=sp[a:b], folder_ids=folder[a:b])
     live = np.ones(n, bool)
@@ -575,6 +575,14 @@ def test_inverted_sparse_scan_equals_the_forward_scan(gpu, monkeypatch, tmp_path
     e.upsert(x[:100], sparse=more, folder_ids=folder[:100])  # appends go on after a compaction
     check(e, sp_c + more, np.ones(keep.size + 100, bool), np.concatenate([folder[keep], folder[:100]]), "appended")
     e.close()
+
+    # many small upserts: each is a segment of its own until there are four times as many as the rows need, then the
+    # whole index is sorted into full segments again (twice on the way to 160 upserts)
+    t = _engine(dim)
+    for a in range(0, 800, 5):
+        t.upsert(x[a:a + 5], sparse=sp[a:a + 5], folder_ids=folder[a:a + 5])
+    check(t, sp[:800], np.ones(800, bool), folder[:800], "small upserts")
+    t.close()
 
     # rows that list a term twice (caller-supplied vectors may; the oracle's statistics count such a term once, the
     # engine's once per entry, so here the two scans are held against each other): both entries count, in row order

@@ -85,8 +85,8 @@ struct SliceDesc {
 };
 
 // One segment of the inverted sparse index (invert.hip): the postings of <= kInvSegRows consecutive rows, sorted
-// by (term, row). A posting is a 64-bit key — bits 0..10 the row inside the segment, bits 11..41 the term id,
-// bits 42.. the segment's number inside its build batch (what the sort groups by) — plus the f32 weight.
+// by (term, row). A posting is a 64-bit key — bits 0..11 the row inside the segment, bits 12..42 the term id,
+// bits 43.. the segment's number inside its build batch (what the sort groups by) — plus the f32 weight.
 struct InvSeg {
   int64_t off;       // first posting (into inv_key / inv_val)
   int32_t count;
@@ -94,9 +94,9 @@ struct InvSeg {
   int32_t nrows;
   int32_t pad;
 };
-constexpr int kInvRowBits = 11;
+constexpr int kInvRowBits = 12;
 constexpr int kInvSegRows = 1 << kInvRowBits;
-constexpr int kInvSubShift = 42;
+constexpr int kInvSubShift = 43;
 constexpr int kInvMaxTerms = 32;   // queries with more distinct terms take the forward (SELL) scan
 
 constexpr int kTileRows = 16;      // corpus rows per MFMA tile (v_mfma_f32_16x16x4_f32 M)
@@ -221,6 +221,7 @@ struct vr_engine {
   int64_t inv_used = 0;      // postings
   int64_t n_inv_seg = 0;
   int64_t inv_slices = 0;    // slices the inverted index covers (== n_slices_dev when usable)
+  int64_t inv_rows = 0;      // rows its segments span
   vr::DevArray<uint64_t> inv_tmp_key;   // build scratch
   vr::DevArray<float> inv_tmp_val;
   vr::DevArray<uint8_t> inv_tmp_sort;
@@ -359,7 +360,7 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
 int inv_rebuild(vr_engine* e);
 void inv_release(vr_engine* e);
 bool inv_usable(const vr_engine* e, int nnz);
-int inv_scan_topk(vr_engine* e, const int32_t* q_idx_dev, const float* q_val_dev, int nnz, bool weights_given,
+int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
                   float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev);
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
                   const uint8_t* mask_dev, bool weights_given);

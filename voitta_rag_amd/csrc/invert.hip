@@ -8,9 +8,10 @@
 // token id, every multiply and add rounded to f32; src/voitta/services/vector_store.py:647-656 is the call this
 // serves):
 //
-//   * rows are cut into SEGMENTS of <= 2048 consecutive rows; a segment holds its postings sorted by (term, row),
+//   * rows are cut into SEGMENTS of <= 4096 consecutive rows; a segment holds its postings sorted by (term, row),
 //     as 64-bit keys (segment number | term id | row inside the segment) with the f32 weights beside them. A batch
-//     of an upsert becomes its own segments (one device radix sort per batch, rocPRIM), nothing is merged later;
+//     of an upsert becomes its own segments (one device radix sort per batch, rocPRIM); when small upserts have
+//     left four times the segments the rows need, the whole collection is sorted into full segments again;
 //   * the query is ONE kernel, a block per segment: the query's terms are located in the segment by 64-way
 //     searches (a wave per term), then taken in ascending term order — the postings of one term name distinct rows,
 //     so the block adds them to a per-row f32 accumulator in LDS without conflicts, a barrier between terms keeps
@@ -33,7 +34,8 @@
 namespace vr {
 
 constexpr int kInvWaves = 4;
-constexpr int kInvGroup = 8;  // terms whose postings a block requests together
+constexpr int kInvGroup = 4;  // terms whose postings a block requests together,
+constexpr int kInvPer = 4;    // postings of each per thread
 constexpr uint64_t kInvTermMask = 0x7FFFFFFFull;
 
 __device__ __forceinline__ int32_t inv_term(uint64_t key) {
@@ -45,7 +47,8 @@ __device__ __forceinline__ int32_t inv_term(uint64_t key) {
 // One wave per slice, lane = row. Real ids form a prefix of a row's column (padding is -1), so a lane counts its
 // entries, the wave reserves room for all of them with one atomic and every lane writes its run.
 __global__ __launch_bounds__(64) void inv_emit_kernel(const SliceDesc* __restrict__ slices, int64_t slice0,
-                                                      int64_t first_row, const int32_t* __restrict__ sidx,
+                                                      int64_t first_row, int seg_rows,
+                                                      const int32_t* __restrict__ sidx,
                                                       const float* __restrict__ sval, uint64_t* __restrict__ keys,
                                                       float* __restrict__ vals, unsigned long long* counter) {
   const SliceDesc d = slices[slice0 + blockIdx.x];
@@ -68,8 +71,7 @@ __global__ __launch_bounds__(64) void inv_emit_kernel(const SliceDesc* __restric
          __shfl(static_cast<unsigned>(base), 0);
   int64_t pos = static_cast<int64_t>(base) + incl - c;
   const int64_t rel = d.row_base + lane - first_row;
-  const uint64_t hi = (static_cast<uint64_t>(rel >> kInvRowBits) << kInvSubShift) |
-                      static_cast<uint64_t>(rel & (kInvSegRows - 1));
+  const uint64_t hi = (static_cast<uint64_t>(rel / seg_rows) << kInvSubShift) | static_cast<uint64_t>(rel % seg_rows);
   for (int j = 0; j < c; ++j) {
     const int64_t src = d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3);
     keys[pos] = hi | (static_cast<uint64_t>(static_cast<uint32_t>(sidx[src])) << kInvRowBits);
@@ -90,7 +92,8 @@ __device__ __forceinline__ int64_t inv_lower_bound(const uint64_t* __restrict__ 
 
 // keys: the sorted postings of one build batch; segment j of the batch = the keys with bits 42.. == j
 __global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n_ent, int64_t base_off,
-                                    int64_t first_row, int64_t n_rows, int n_sub, InvSeg* __restrict__ out) {
+                                    int64_t first_row, int64_t n_rows, int seg_rows, int n_sub,
+                                    InvSeg* __restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_sub) return;
   const int64_t lo = inv_lower_bound(keys, n_ent, static_cast<uint64_t>(j) << kInvSubShift);
@@ -98,9 +101,9 @@ __global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n
   InvSeg s;
   s.off = base_off + lo;
   s.count = static_cast<int32_t>(hi - lo);
-  s.row_base = static_cast<int32_t>(first_row + static_cast<int64_t>(j) * kInvSegRows);
-  const int64_t left = n_rows - static_cast<int64_t>(j) * kInvSegRows;
-  s.nrows = static_cast<int32_t>(left < kInvSegRows ? left : kInvSegRows);
+  s.row_base = static_cast<int32_t>(first_row + static_cast<int64_t>(j) * seg_rows);
+  const int64_t left = n_rows - static_cast<int64_t>(j) * seg_rows;
+  s.nrows = static_cast<int32_t>(left < seg_rows ? left : seg_rows);
   s.pad = 0;
   out[j] = s;
 }
@@ -117,6 +120,7 @@ void inv_release(vr_engine* e) {
   e->inv_used = 0;
   e->n_inv_seg = 0;
   e->inv_slices = 0;
+  e->inv_rows = 0;
 }
 
 int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, int64_t n_rows, int64_t nnz) {
@@ -126,19 +130,21 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
   VR_CHECK(n_rows >= 1 && n_rows < (1ll << 31) && slice0 + n_new <= static_cast<int64_t>(e->slices_host.size()),
            "bad inverted-index batch");
   const SliceDesc& last = e->slices_host[static_cast<size_t>(slice0 + n_new - 1)];
-  const int64_t room = nnz < 0 ? e->sp_used  // rebuild from a file: no assumption about the order of the slices
+  const int64_t room = nnz < 0 ? std::max<int64_t>(e->sp_used, 1)  // rebuild from a file: no assumption about the order of the slices
                                : last.off + static_cast<int64_t>(last.width) * 64 -
                                      e->slices_host[static_cast<size_t>(slice0)].off;
   const int64_t n_sub = (n_rows + kInvSegRows - 1) / kInvSegRows;
+  const int seg_rows = static_cast<int>((n_rows + n_sub - 1) / n_sub);  // equal parts: no sliver of a segment at the end
   if (!e->inv_counter) VR_HIP(hipMalloc(reinterpret_cast<void**>(&e->inv_counter), sizeof(unsigned long long)));
   VR_HIP(hipMemsetAsync(e->inv_counter, 0, sizeof(unsigned long long), e->stream));
   VR_TRY(e->inv_tmp_key.grow(std::max<int64_t>(room, 1), 0, e->stream));
   VR_TRY(e->inv_tmp_val.grow(std::max<int64_t>(room, 1), 0, e->stream));
   hipLaunchKernelGGL(inv_emit_kernel, dim3(static_cast<unsigned>(n_new)), dim3(64), 0, e->stream, e->slices.p,
-                     slice0, first_row, e->sp_idx.p, e->sp_val.p, e->inv_tmp_key.p, e->inv_tmp_val.p,
+                     slice0, first_row, seg_rows, e->sp_idx.p, e->sp_val.p, e->inv_tmp_key.p, e->inv_tmp_val.p,
                      e->inv_counter);
   VR_HIP(hipGetLastError());
-  if (nnz < 0) {  // rebuild: only the device knows how many entries are real
+  const bool rebuilding = nnz < 0;
+  if (rebuilding) {  // only the device knows how many entries are real
     unsigned long long c = 0;
     VR_HIP(hipMemcpyAsync(&c, e->inv_counter, sizeof(c), hipMemcpyDeviceToHost, e->stream));
     VR_HIP(hipStreamSynchronize(e->stream));
@@ -163,12 +169,18 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
                                      end_bit, e->stream));
   }
   hipLaunchKernelGGL(inv_segments_kernel, dim3(static_cast<unsigned>((n_sub + 255) / 256)), dim3(256), 0, e->stream,
-                     e->inv_key.p + e->inv_used, nnz, e->inv_used, first_row, n_rows, static_cast<int>(n_sub),
+                     e->inv_key.p + e->inv_used, nnz, e->inv_used, first_row, n_rows, seg_rows, static_cast<int>(n_sub),
                      e->inv_seg.p + e->n_inv_seg);
   VR_HIP(hipGetLastError());
   e->inv_used += nnz;
   e->n_inv_seg += n_sub;
   e->inv_slices = slice0 + n_new;
+  e->inv_rows += n_rows;
+  // Many small upserts leave many small segments, and a query pays a chain of dependent loads per segment: once
+  // there are four times as many as rows / 4096 needs, sort the whole collection into full segments again (the
+  // interval between two such rebuilds grows with the collection, like the re-centring of the int8 shadow).
+  if (!rebuilding && e->n_inv_seg > 64 && e->n_inv_seg > 4 * ((e->inv_rows + kInvSegRows - 1) / kInvSegRows))
+    return inv_rebuild(e);
   return 0;
 }
 
@@ -176,6 +188,7 @@ int inv_rebuild(vr_engine* e) {
   e->inv_used = 0;
   e->n_inv_seg = 0;
   e->inv_slices = 0;
+  e->inv_rows = 0;
   const int64_t n = static_cast<int64_t>(e->slices_host.size());
   if (n == 0) return 0;
   int64_t first = e->slices_host.front().row_base, end = first;
@@ -225,9 +238,15 @@ __device__ __forceinline__ int inv_wave_lower_bound(const uint64_t* __restrict__
   return lo + __popcll(__ballot(less));
 }
 
+// the query travels in the kernel arguments: scalar loads, no trip to the host's pinned memory per block
+struct InvQuery {
+  int32_t id[kInvMaxTerms];
+  float val[kInvMaxTerms];
+};
+
 __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
-    const int32_t* __restrict__ q_idx, const float* __restrict__ q_val, int nnz, int weights_given,
+    const InvQuery query, int nnz, int weights_given,
     const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
     const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
   __shared__ float score[kInvSegRows];
@@ -236,14 +255,16 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
   __shared__ float t_w[kInvMaxTerms];
   __shared__ int32_t t_lo[kInvMaxTerms];
   __shared__ uint64_t lists[kInvWaves * kListLen];
+  __shared__ uint64_t tmax[kInvWaves * 64];
+  __shared__ uint64_t blk_thr;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   uint64_t* list = lists + wave * kListLen;
   lists[threadIdx.x] = 0ull;  // blockDim.x == kInvWaves * kListLen
   if (static_cast<int>(threadIdx.x) < nnz) {
-    const int32_t id = q_idx[threadIdx.x];
+    const int32_t id = query.id[threadIdx.x];
     t_id[threadIdx.x] = id;
-    t_w[threadIdx.x] = sparse_query_weight(q_val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
+    t_w[threadIdx.x] = sparse_query_weight(query.val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
   }
   __syncthreads();
 
@@ -262,20 +283,24 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     }
     __syncthreads();
     // Ascending term id: the forward scan's summation order. The postings of kInvGroup terms are requested
-    // together (a thread takes posting t_lo + tid of each: all addresses are known), so the terms that follow cost
-    // LDS work only; a term with more than 256 postings in this segment, or a row that lists it twice, takes the
-    // general loop below.
+    // together (a thread takes postings t_lo + tid + 256 u, u < kInvPer, of each: all addresses are known), so the
+    // terms that follow cost LDS work only; a term with more than 256 kInvPer postings in this segment, or a row
+    // that lists it twice, takes the general loop below.
     for (int g0 = 0; g0 < nnz; g0 += kInvGroup) {
-      uint64_t key[kInvGroup], prv[kInvGroup];
-      float val[kInvGroup];
+      uint64_t key[kInvGroup][kInvPer], prv[kInvGroup][kInvPer];
+      float val[kInvGroup][kInvPer];
 #pragma unroll
       for (int u = 0; u < kInvGroup; ++u) {
         const int i = g0 + u;
-        const int p = (i < nnz ? t_lo[i] : 0) + static_cast<int>(threadIdx.x);
-        const int pc = (i < nnz && p < seg.count) ? p : 0;
-        key[u] = kp[pc];
-        val[u] = vp[pc];
-        prv[u] = pc ? kp[pc - 1] : ~0ull;
+        const int base = (i < nnz ? t_lo[i] : 0) + static_cast<int>(threadIdx.x);
+#pragma unroll
+        for (int v = 0; v < kInvPer; ++v) {
+          const int p = base + v * kInvWaves * 64;
+          const int pc = (i < nnz && p < seg.count) ? p : 0;
+          key[u][v] = kp[pc];
+          val[u][v] = vp[pc];
+          prv[u][v] = pc ? kp[pc - 1] : ~0ull;
+        }
       }
 #pragma unroll
       for (int u = 0; u < kInvGroup; ++u) {
@@ -283,15 +308,23 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
         if (i >= nnz) break;  // block-uniform
         const int32_t t = t_id[i];
         const float w = t_w[i];
-        const int p0 = t_lo[i] + static_cast<int>(threadIdx.x);
-        const bool mine = p0 < seg.count && inv_term(key[u]) == t;
-        const bool general = mine && (prv[u] == key[u] || threadIdx.x == kInvWaves * 64 - 1);
+        const int base = t_lo[i] + static_cast<int>(threadIdx.x);
+        bool mine[kInvPer];
+        bool general = false;
+#pragma unroll
+        for (int v = 0; v < kInvPer; ++v) {
+          mine[v] = base + v * kInvWaves * 64 < seg.count && inv_term(key[u][v]) == t;
+          general = general || (mine[v] && prv[u][v] == key[u][v]);
+        }
+        general = general || (mine[kInvPer - 1] && threadIdx.x == kInvWaves * 64 - 1);  // the run may go on
         if (!__syncthreads_or(general)) {  // (the barrier also orders this term after the one before)
-          if (mine) {
-            const int r = static_cast<int>(key[u] & (kInvSegRows - 1));
-            score[r] = __fadd_rn(score[r], __fmul_rn(w, val[u]));
-            hit[r] = 1;
-          }
+#pragma unroll
+          for (int v = 0; v < kInvPer; ++v)
+            if (mine[v]) {
+              const int r = static_cast<int>(key[u][v] & (kInvSegRows - 1));
+              score[r] = __fadd_rn(score[r], __fmul_rn(w, val[u][v]));
+              hit[r] = 1;
+            }
           continue;
         }
         for (int p = t_lo[i] + wave * 64 + lane;; p += kInvWaves * 64) {
@@ -317,13 +350,35 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
         }
       }
     }
+    if (threadIdx.x == 0) blk_thr = 0ull;
     __syncthreads();
-    for (int r0 = wave * 64; r0 < seg.nrows; r0 += kInvWaves * 64) {
-      const int r = r0 + lane;
+    // Selection. Thousands of rows may have been hit and a list insert is serial work for its wave, so first a
+    // bound: a thread takes rows tid, tid + 256, ...; the k-th largest of the 256 per-thread maxima has k keys at or
+    // above it (keys are unique: they carry the row), so only keys that reach it can be among the segment's k best.
+    uint64_t rkey[kInvSegRows / (kInvWaves * 64)];
+    uint64_t best = 0ull;
+#pragma unroll
+    for (int j = 0; j < kInvSegRows / (kInvWaves * 64); ++j) {
+      const int r = static_cast<int>(threadIdx.x) + j * kInvWaves * 64;
       const bool in = r < seg.nrows && hit[r];
       const int64_t row = static_cast<int64_t>(seg.row_base) + r;
-      const bool ok = in && mask[row];
-      wave_offer(list, k, ok ? topk_make_key(score[r], row) : 0ull, 0, ok, lane);
+      rkey[j] = (in && mask[row]) ? topk_make_key(score[r], row) : 0ull;
+      best = rkey[j] > best ? rkey[j] : best;
+    }
+    tmax[threadIdx.x] = best;
+    __syncthreads();
+    if (best) {
+      int rank = 0;
+      for (int j = 0; j < kInvWaves * 64; ++j) rank += tmax[j] > best;
+      if (rank == k - 1) blk_thr = best;
+    }
+    __syncthreads();
+    const uint64_t thr = blk_thr;
+#pragma unroll
+    for (int j = 0; j < kInvSegRows / (kInvWaves * 64); ++j) {
+      if (j * kInvWaves * 64 >= seg.nrows) break;  // block-uniform
+      const bool ok = rkey[j] != 0ull && rkey[j] >= thr;
+      wave_offer(list, k, rkey[j], 0, ok, lane);
     }
     __syncthreads();  // the next segment clears the accumulators
   }
@@ -331,17 +386,22 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
   if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
 }
 
-int inv_scan_topk(vr_engine* e, const int32_t* q_idx_dev, const float* q_val_dev, int nnz, bool weights_given,
+int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
                   float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev) {
   VR_CHECK(nnz >= 1 && nnz <= kInvMaxTerms && k >= 1 && k <= kListLen, "bad inverted-scan shape");
+  InvQuery query;
+  for (int i = 0; i < kInvMaxTerms; ++i) {
+    query.id[i] = i < nnz ? q_idx_host[i] : 0;
+    query.val[i] = i < nnz ? q_val_host[i] : 0.0f;
+  }
   const int blocks = static_cast<int>(std::min<int64_t>(e->n_inv_seg, kScanBlocks));
   VR_TRY(e->sp_cand.grow(static_cast<int64_t>(blocks) * kListLen, 0, e->stream));
   // work 0: the postings the query's terms own are counted nowhere on the host (the slot's time and launch count
   // are what bench.py reads for this scan)
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
   hipLaunchKernelGGL(sparse_inv_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kInvWaves * 64), 0, e->stream,
-                     e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_idx_dev, q_val_dev,
-                     nnz, weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev, k,
+                     e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, query, nnz,
+                     weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev, k,
                      e->sp_cand.p);
   prof_end(e);
   VR_HIP(hipGetLastError());

@@ -333,7 +333,7 @@ static int sparse_run(vr_engine* e, const int32_t* q_idx_host, const float* q_va
   const float* dval = pin_dev<float>(e, kPinSparseVals);
   const float n_points = static_cast<float>(e->n_sparse_points);
   if (fused_k && inv_usable(e, nnz))  // a few terms: their postings only
-    return inv_scan_topk(e, did, dval, nnz, weights_given, n_points, mask_dev, fused_k, out_keys_dev);
+    return inv_scan_topk(e, hid, hval, nnz, weights_given, n_points, mask_dev, fused_k, out_keys_dev);
   if (fused_k) {
     int64_t blocks = std::min<int64_t>((e->n_slices_dev + kSparseWaves - 1) / kSparseWaves, kScanBlocks);
     if (blocks < 1) blocks = 1;
