@@ -18,8 +18,6 @@ with tempfile.TemporaryDirectory() as tmp:
             get = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
             name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
-            if "rocprim::" in name:  # the library sort of the index build (invert.hip): not ours, not on a latency path
-                continue
             scratch = get("private_segment_fixed_size")
             bad += scratch > 0
             print(f"{base:8s} {name[:58]:58s} vgpr {get('vgpr_count'):4d} lds {get('group_segment_fixed_size'):7d} "

@@ -585,7 +585,8 @@ def test_inverted_sparse_scan_equals_the_forward_scan(gpu, monkeypatch, tmp_path
     t.close()
 
     # rows that list a term twice (caller-supplied vectors may; the oracle's statistics count such a term once, the
-    # engine's once per entry, so here the two scans are held against each other): both entries count, in row order
+    # engine's once per entry, so here the engine is held against its own forward scan): both entries count, in row
+    # order — the engine notices such rows and keeps the collection on the forward scan
     d = _engine(dim)
     rows = _sparse_rows(rng, 300, vocab=40, lo=2, hi=12)
     for r in range(0, 300, 3):
@@ -600,5 +601,17 @@ def test_inverted_sparse_scan_equals_the_forward_scan(gpu, monkeypatch, tmp_path
         monkeypatch.setenv("VR_SPARSE_INVERTED", "0")
         fr, fs = d.search_sparse(qi, qv, 64)
         assert len(gr) > 0 and np.array_equal(gr, fr) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32))
+    # ... and a file of such rows is recognised when it is loaded (the index is rebuilt from the slices there)
+    d.save(path)
+    d2 = _engine(dim)
+    d2.load(path)
+    for trial in range(8):
+        qi = (rng.choice(40, size=5, replace=False).astype(np.int32) * 7919 + 13)
+        qv = rng.uniform(0.5, 1.5, size=5).astype(np.float32)
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+        gr, gs = d2.search_sparse(qi, qv, 64)
+        fr, fs = d.search_sparse(qi, qv, 64)
+        assert len(gr) > 0 and np.array_equal(gr, fr) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32))
+    d2.close()
     monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
     d.close()

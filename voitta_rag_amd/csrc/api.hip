@@ -211,6 +211,7 @@ static void lane_view(vr_engine* L, const vr_engine* m) {
   L->inv_used = m->inv_used;
   L->n_inv_seg = m->n_inv_seg;
   L->inv_slices = m->inv_slices;
+  L->sp_has_dups = m->sp_has_dups;
   L->df_keys = m->df_keys;
   L->df_cnt = m->df_cnt;
   L->df_cap = m->df_cap;
@@ -538,6 +539,8 @@ static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, c
         tmp.clear();
         for (int64_t j = b; j < en; ++j) tmp.emplace_back(idx[static_cast<size_t>(j)], val[static_cast<size_t>(j)]);
         std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+        for (size_t j = 1; j < tmp.size(); ++j)
+          if (tmp[j - 1].first == tmp[j].first) e->sp_has_dups = true;  // a term listed twice (invert.hip)
         for (int64_t j = b; j < en; ++j) {
           idx[static_cast<size_t>(j)] = tmp[static_cast<size_t>(j - b)].first;
           val[static_cast<size_t>(j)] = tmp[static_cast<size_t>(j - b)].second;
@@ -566,9 +569,12 @@ static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, c
       VR_TRY(sparse_append(e, n, first, cnt.data(), sp_off, sp_cnt_dev, sp_idx, sp_val));
     } else {
       std::vector<int64_t> off_host(static_cast<size_t>(n + 1));
+      unsigned long long dups = 0;
+      VR_TRY(inv_note_csr_dups(e, sp_off, sp_idx, n, &dups));
       VR_HIP(hipMemcpyAsync(off_host.data(), sp_off, sizeof(int64_t) * static_cast<size_t>(n + 1),
                             hipMemcpyDeviceToHost, e->stream));
       VR_HIP(hipStreamSynchronize(e->stream));
+      if (dups) e->sp_has_dups = true;
       VR_CHECK(off_host[0] == 0, "sparse offsets must start at 0");
       std::vector<int32_t> cnt(static_cast<size_t>(n));
       for (int64_t r = 0; r < n; ++r) {

@@ -222,10 +222,8 @@ struct vr_engine {
   int64_t n_inv_seg = 0;
   int64_t inv_slices = 0;    // slices the inverted index covers (== n_slices_dev when usable)
   int64_t inv_rows = 0;      // rows its segments span
-  vr::DevArray<uint64_t> inv_tmp_key;   // build scratch
-  vr::DevArray<float> inv_tmp_val;
-  vr::DevArray<uint8_t> inv_tmp_sort;
-  unsigned long long* inv_counter = nullptr;
+  unsigned long long* inv_counter = nullptr;  // [0] postings emitted by the current build, [1] duplicates seen
+  bool sp_has_dups = false;  // some row lists a term twice: queries stay on the forward scan
 
   // document-frequency table: open addressing, key -1 = empty
   vr::DevArray<int32_t> df_keys;
@@ -358,6 +356,10 @@ int bm25_tf(vr_engine* e, const int64_t* tok_off_dev, const int32_t* tok_ids_dev
 // entries, or -1 to have the device count them), and the one-kernel query over it
 int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, int64_t n_rows, int64_t nnz);
 int inv_rebuild(vr_engine* e);
+// rows of a caller's device CSR batch (sorted by id) that list a term twice: the count so far arrives in *out_host
+// once the stream has been synchronised
+int inv_note_csr_dups(vr_engine* e, const int64_t* off_dev, const int32_t* idx_dev, int64_t n,
+                      unsigned long long* out_host);
 void inv_release(vr_engine* e);
 bool inv_usable(const vr_engine* e, int nnz);
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,

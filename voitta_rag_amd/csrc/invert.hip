@@ -10,8 +10,8 @@
 //
 //   * rows are cut into SEGMENTS of <= 4096 consecutive rows; a segment holds its postings sorted by (term, row),
 //     as 64-bit keys (segment number | term id | row inside the segment) with the f32 weights beside them. A batch
-//     of an upsert becomes its own segments (one device radix sort per batch, rocPRIM); when small upserts have
-//     left four times the segments the rows need, the whole collection is sorted into full segments again;
+//     of an upsert becomes its own segments (one bitonic sort per batch, below); when small upserts have left four
+//     times the segments the rows need, the whole collection is sorted into full segments again;
 //   * the query is ONE kernel, a block per segment: the query's terms are located in the segment by 64-way
 //     searches (a wave per term), then taken in ascending term order — the postings of one term name distinct rows,
 //     so the block adds them to a per-row f32 accumulator in LDS without conflicts, a barrier between terms keeps
@@ -19,14 +19,14 @@
 //     through the same per-wave top-k lists as every fused scan; merge_lists_kernel finishes.
 //
 // Algorithmic bytes: 12 B per posting of the query's terms + one mask byte per hit row; at a million rows and
-// five Zipf-head terms ≈ 20 MB instead of 166 MB. Queries with more than kInvMaxTerms distinct terms, k > 64,
-// and the all-scores entry point keep the forward scan (its cost does not grow with the number of terms).
+// five Zipf-head terms ≈ 15 MB instead of 166 MB. Queries with more than kInvMaxTerms distinct terms, k > 64,
+// the all-scores entry point, and collections in which some row lists a term twice (caller-supplied vectors may;
+// the order of such a pair inside the sum is the row's own, which the sort here does not keep) stay on the forward
+// scan (its cost does not grow with the number of terms).
 
 #include "engine_internal.h"
 #include "sparse_device.h"
 #include "topk_device.h"
-
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -80,6 +80,96 @@ __global__ __launch_bounds__(64) void inv_emit_kernel(const SliceDesc* __restric
   }
 }
 
+// The sort of a batch's postings by key: a bitonic network over the batch padded to a power of two with keys of all
+// ones. Data independent (caller-supplied term ids are not hashes), in place, and off every latency path: a batch of
+// 2200 chunks (88k postings) is 21 small launches, a million rows (40M) about a hundred passes over 0.8 GB. Equal
+// keys (a row that lists a term twice) may change places — such collections do not use this index (sp_has_dups).
+constexpr int kSortTile = 4096;     // postings a block sorts in LDS (48 KiB)
+constexpr int kSortThreads = 1024;
+
+__global__ void inv_pad_kernel(uint64_t* __restrict__ keys, float* __restrict__ vals, int64_t from, int64_t to) {
+  const int64_t i = from + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < to) {
+    keys[i] = ~0ull;
+    vals[i] = 0.0f;
+  }
+}
+
+// FULL: every stage up to the tile size (a sorted tile, ascending or descending by the tile's place in the
+// network); otherwise the strides below the tile size of stage `size`.
+template <bool FULL>
+__global__ __launch_bounds__(kSortThreads) void bitonic_tile_kernel(uint64_t* __restrict__ keys,
+                                                                    float* __restrict__ vals, int64_t size) {
+  __shared__ uint64_t k[kSortTile];
+  __shared__ float v[kSortTile];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+#pragma unroll
+  for (int j = 0; j < kSortTile / kSortThreads; ++j) {
+    const int i = static_cast<int>(threadIdx.x) + j * kSortThreads;
+    k[i] = keys[base + i];
+    v[i] = vals[base + i];
+  }
+  __syncthreads();
+  for (int64_t sz = FULL ? 2 : size; sz <= (FULL ? static_cast<int64_t>(kSortTile) : size); sz <<= 1) {
+    for (int st = static_cast<int>(sz < kSortTile ? sz : kSortTile) >> 1; st > 0; st >>= 1) {
+#pragma unroll
+      for (int j = 0; j < kSortTile / 2 / kSortThreads; ++j) {
+        const int t = static_cast<int>(threadIdx.x) + j * kSortThreads;
+        const int i = ((t & ~(st - 1)) << 1) | (t & (st - 1));
+        const int l = i + st;
+        const bool asc = ((base + i) & sz) == 0;
+        const uint64_t a = k[i], b2 = k[l];
+        if ((a > b2) == asc) {
+          k[i] = b2;
+          k[l] = a;
+          const float f = v[i];
+          v[i] = v[l];
+          v[l] = f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSortTile / kSortThreads; ++j) {
+    const int i = static_cast<int>(threadIdx.x) + j * kSortThreads;
+    keys[base + i] = k[i];
+    vals[base + i] = v[i];
+  }
+}
+
+// one compare-exchange pass of stage `size` at a stride of at least the tile size
+__global__ __launch_bounds__(256) void bitonic_global_kernel(uint64_t* __restrict__ keys, float* __restrict__ vals,
+                                                             int64_t half, int64_t size, int64_t stride) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= half) return;
+  const int64_t i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+  const int64_t l = i + stride;
+  const bool asc = (i & size) == 0;
+  const uint64_t a = keys[i], b = keys[l];
+  if ((a > b) == asc) {
+    keys[i] = b;
+    keys[l] = a;
+    const float f = vals[i];
+    vals[i] = vals[l];
+    vals[l] = f;
+  }
+}
+
+static int inv_sort(vr_engine* e, uint64_t* keys, float* vals, int64_t n_pad) {
+  const unsigned tiles = static_cast<unsigned>(n_pad / kSortTile);
+  hipLaunchKernelGGL((bitonic_tile_kernel<true>), dim3(tiles), dim3(kSortThreads), 0, e->stream, keys, vals,
+                     static_cast<int64_t>(0));
+  for (int64_t size = 2 * kSortTile; size <= n_pad; size <<= 1) {
+    for (int64_t stride = size >> 1; stride >= kSortTile; stride >>= 1)
+      hipLaunchKernelGGL(bitonic_global_kernel, dim3(static_cast<unsigned>((n_pad / 2 + 255) / 256)), dim3(256), 0,
+                         e->stream, keys, vals, n_pad / 2, size, stride);
+    hipLaunchKernelGGL((bitonic_tile_kernel<false>), dim3(tiles), dim3(kSortThreads), 0, e->stream, keys, vals, size);
+  }
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
 __device__ __forceinline__ int64_t inv_lower_bound(const uint64_t* __restrict__ keys, int64_t n, uint64_t target) {
   int64_t lo = 0, hi = n;
   while (lo < hi) {
@@ -90,7 +180,7 @@ __device__ __forceinline__ int64_t inv_lower_bound(const uint64_t* __restrict__ 
   return lo;
 }
 
-// keys: the sorted postings of one build batch; segment j of the batch = the keys with bits 42.. == j
+// keys: the sorted postings of one build batch; segment j of the batch = the keys with bits 43.. == j
 __global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n_ent, int64_t base_off,
                                     int64_t first_row, int64_t n_rows, int seg_rows, int n_sub,
                                     InvSeg* __restrict__ out) {
@@ -108,13 +198,47 @@ __global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n
   out[j] = s;
 }
 
+// counter[1] += postings equal to their left neighbour (a row that lists a term twice)
+__global__ void inv_count_dups_kernel(const uint64_t* __restrict__ keys, int64_t n, unsigned long long* counter) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= 1 && i < n && keys[i] == keys[i - 1]) atomicAdd(counter + 1, 1ull);
+}
+
+// the same question asked of a CSR batch whose rows are sorted by id (a caller's device arrays)
+__global__ void inv_csr_dups_kernel(const int64_t* __restrict__ off, const int32_t* __restrict__ idx, int64_t n,
+                                    unsigned long long* counter) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int64_t j = off[r] + 1; j < off[r + 1]; ++j)
+    if (idx[j] == idx[j - 1]) {
+      atomicAdd(counter + 1, 1ull);
+      return;
+    }
+}
+
+static int inv_counters(vr_engine* e) {
+  if (!e->inv_counter) {
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&e->inv_counter), 2 * sizeof(unsigned long long)));
+    VR_HIP(hipMemsetAsync(e->inv_counter, 0, 2 * sizeof(unsigned long long), e->stream));
+  }
+  return 0;
+}
+
+int inv_note_csr_dups(vr_engine* e, const int64_t* off_dev, const int32_t* idx_dev, int64_t n,
+                      unsigned long long* out_host) {
+  VR_TRY(inv_counters(e));
+  if (n > 0)
+    hipLaunchKernelGGL(inv_csr_dups_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream,
+                       off_dev, idx_dev, n, e->inv_counter);
+  VR_HIP(hipGetLastError());
+  VR_HIP(hipMemcpyAsync(out_host, e->inv_counter + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  return 0;  // the caller synchronises the stream before it reads *out_host
+}
+
 void inv_release(vr_engine* e) {
   e->inv_key.release();
   e->inv_val.release();
   e->inv_seg.release();
-  e->inv_tmp_key.release();
-  e->inv_tmp_val.release();
-  e->inv_tmp_sort.release();
   if (e->inv_counter) (void)hipFree(e->inv_counter);
   e->inv_counter = nullptr;
   e->inv_used = 0;
@@ -129,47 +253,46 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
            static_cast<long long>(e->inv_slices), static_cast<long long>(slice0));
   VR_CHECK(n_rows >= 1 && n_rows < (1ll << 31) && slice0 + n_new <= static_cast<int64_t>(e->slices_host.size()),
            "bad inverted-index batch");
-  const SliceDesc& last = e->slices_host[static_cast<size_t>(slice0 + n_new - 1)];
-  const int64_t room = nnz < 0 ? std::max<int64_t>(e->sp_used, 1)  // rebuild from a file: no assumption about the order of the slices
-                               : last.off + static_cast<int64_t>(last.width) * 64 -
-                                     e->slices_host[static_cast<size_t>(slice0)].off;
+  const bool rebuilding = nnz < 0;  // (then only the device knows how many entries are real)
+  const int64_t room = rebuilding ? std::max<int64_t>(e->sp_used, 1)  // no assumption about the order of a file's slices
+                                  : std::max<int64_t>(nnz, 1);
   const int64_t n_sub = (n_rows + kInvSegRows - 1) / kInvSegRows;
   const int seg_rows = static_cast<int>((n_rows + n_sub - 1) / n_sub);  // equal parts: no sliver of a segment at the end
-  if (!e->inv_counter) VR_HIP(hipMalloc(reinterpret_cast<void**>(&e->inv_counter), sizeof(unsigned long long)));
+  int64_t n_pad = kSortTile;
+  while (n_pad < room) n_pad <<= 1;
+  VR_TRY(inv_counters(e));
   VR_HIP(hipMemsetAsync(e->inv_counter, 0, sizeof(unsigned long long), e->stream));
-  VR_TRY(e->inv_tmp_key.grow(std::max<int64_t>(room, 1), 0, e->stream));
-  VR_TRY(e->inv_tmp_val.grow(std::max<int64_t>(room, 1), 0, e->stream));
+  // emitted and sorted in place, behind the postings already there (the padding of the sort is overwritten by the
+  // next batch)
+  VR_TRY(e->inv_key.grow(e->inv_used + n_pad, e->inv_used, e->stream));
+  VR_TRY(e->inv_val.grow(e->inv_used + n_pad, e->inv_used, e->stream));
+  VR_TRY(e->inv_seg.grow(e->n_inv_seg + n_sub, e->n_inv_seg, e->stream));
+  uint64_t* keys = e->inv_key.p + e->inv_used;
+  float* vals = e->inv_val.p + e->inv_used;
   hipLaunchKernelGGL(inv_emit_kernel, dim3(static_cast<unsigned>(n_new)), dim3(64), 0, e->stream, e->slices.p,
-                     slice0, first_row, seg_rows, e->sp_idx.p, e->sp_val.p, e->inv_tmp_key.p, e->inv_tmp_val.p,
-                     e->inv_counter);
+                     slice0, first_row, seg_rows, e->sp_idx.p, e->sp_val.p, keys, vals, e->inv_counter);
   VR_HIP(hipGetLastError());
-  const bool rebuilding = nnz < 0;
-  if (rebuilding) {  // only the device knows how many entries are real
+  if (rebuilding) {
     unsigned long long c = 0;
     VR_HIP(hipMemcpyAsync(&c, e->inv_counter, sizeof(c), hipMemcpyDeviceToHost, e->stream));
     VR_HIP(hipStreamSynchronize(e->stream));
     nnz = static_cast<int64_t>(c);
+    VR_CHECK(nnz <= room, "inverted-index rebuild: %lld entries in %lld slots", static_cast<long long>(nnz),
+             static_cast<long long>(room));
+    n_pad = kSortTile;
+    while (n_pad < nnz) n_pad <<= 1;
   }
-  VR_CHECK(nnz <= room, "inverted-index batch of %lld entries in %lld slots", static_cast<long long>(nnz),
-           static_cast<long long>(room));
-  VR_TRY(e->inv_key.grow(std::max<int64_t>(e->inv_used + nnz, 1), e->inv_used, e->stream));
-  VR_TRY(e->inv_val.grow(std::max<int64_t>(e->inv_used + nnz, 1), e->inv_used, e->stream));
-  VR_TRY(e->inv_seg.grow(e->n_inv_seg + n_sub, e->n_inv_seg, e->stream));
   if (nnz > 0) {
-    int sub_bits = 1;
-    while ((1ll << sub_bits) < n_sub) ++sub_bits;
-    const unsigned end_bit = static_cast<unsigned>(kInvSubShift + sub_bits);
-    size_t tmp_bytes = 0;
-    VR_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, e->inv_tmp_key.p, e->inv_key.p + e->inv_used,
-                                     e->inv_tmp_val.p, e->inv_val.p + e->inv_used, static_cast<size_t>(nnz), 0u,
-                                     end_bit, e->stream));
-    VR_TRY(e->inv_tmp_sort.grow(static_cast<int64_t>(std::max<size_t>(tmp_bytes, 1)), 0, e->stream));
-    VR_HIP(rocprim::radix_sort_pairs(e->inv_tmp_sort.p, tmp_bytes, e->inv_tmp_key.p, e->inv_key.p + e->inv_used,
-                                     e->inv_tmp_val.p, e->inv_val.p + e->inv_used, static_cast<size_t>(nnz), 0u,
-                                     end_bit, e->stream));
+    if (n_pad > nnz)
+      hipLaunchKernelGGL(inv_pad_kernel, dim3(static_cast<unsigned>((n_pad - nnz + 255) / 256)), dim3(256), 0,
+                         e->stream, keys, vals, nnz, n_pad);
+    VR_TRY(inv_sort(e, keys, vals, n_pad));
+    if (rebuilding)
+      hipLaunchKernelGGL(inv_count_dups_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0,
+                         e->stream, keys, nnz, e->inv_counter);
   }
   hipLaunchKernelGGL(inv_segments_kernel, dim3(static_cast<unsigned>((n_sub + 255) / 256)), dim3(256), 0, e->stream,
-                     e->inv_key.p + e->inv_used, nnz, e->inv_used, first_row, n_rows, seg_rows, static_cast<int>(n_sub),
+                     keys, nnz, e->inv_used, first_row, n_rows, seg_rows, static_cast<int>(n_sub),
                      e->inv_seg.p + e->n_inv_seg);
   VR_HIP(hipGetLastError());
   e->inv_used += nnz;
@@ -201,11 +324,10 @@ int inv_rebuild(vr_engine* e) {
     return 0;
   }
   VR_TRY(inv_append(e, 0, n, first, end - first, -1));
-  // the build scratch of a whole collection is large; batches that follow are small
+  unsigned long long dups = 0;
+  VR_HIP(hipMemcpyAsync(&dups, e->inv_counter + 1, sizeof(dups), hipMemcpyDeviceToHost, e->stream));
   VR_HIP(hipStreamSynchronize(e->stream));
-  e->inv_tmp_key.release();
-  e->inv_tmp_val.release();
-  e->inv_tmp_sort.release();
+  if (dups) e->sp_has_dups = true;
   return 0;
 }
 
@@ -217,7 +339,8 @@ static bool inv_enabled() {
 }
 
 bool inv_usable(const vr_engine* e, int nnz) {
-  return inv_enabled() && nnz >= 1 && nnz <= kInvMaxTerms && e->n_inv_seg > 0 && e->inv_slices == e->n_slices_dev;
+  return inv_enabled() && !e->sp_has_dups && nnz >= 1 && nnz <= kInvMaxTerms && e->n_inv_seg > 0 &&
+         e->inv_slices == e->n_slices_dev;
 }
 
 // Lower bound of term t among the keys of a segment, found by the whole wave: 64 probes per step.
@@ -284,10 +407,10 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     __syncthreads();
     // Ascending term id: the forward scan's summation order. The postings of kInvGroup terms are requested
     // together (a thread takes postings t_lo + tid + 256 u, u < kInvPer, of each: all addresses are known), so the
-    // terms that follow cost LDS work only; a term with more than 256 kInvPer postings in this segment, or a row
-    // that lists it twice, takes the general loop below.
+    // terms that follow cost LDS work only; a term with more than 256 kInvPer postings in this segment takes the
+    // general loop below. (No row lists a term twice here: sp_has_dups keeps such collections on the forward scan.)
     for (int g0 = 0; g0 < nnz; g0 += kInvGroup) {
-      uint64_t key[kInvGroup][kInvPer], prv[kInvGroup][kInvPer];
+      uint64_t key[kInvGroup][kInvPer];
       float val[kInvGroup][kInvPer];
 #pragma unroll
       for (int u = 0; u < kInvGroup; ++u) {
@@ -299,7 +422,6 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
           const int pc = (i < nnz && p < seg.count) ? p : 0;
           key[u][v] = kp[pc];
           val[u][v] = vp[pc];
-          prv[u][v] = pc ? kp[pc - 1] : ~0ull;
         }
       }
 #pragma unroll
@@ -314,9 +436,8 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
 #pragma unroll
         for (int v = 0; v < kInvPer; ++v) {
           mine[v] = base + v * kInvWaves * 64 < seg.count && inv_term(key[u][v]) == t;
-          general = general || (mine[v] && prv[u][v] == key[u][v]);
         }
-        general = general || (mine[kInvPer - 1] && threadIdx.x == kInvWaves * 64 - 1);  // the run may go on
+        general = mine[kInvPer - 1] && threadIdx.x == kInvWaves * 64 - 1;  // the run may go on
         if (!__syncthreads_or(general)) {  // (the barrier also orders this term after the one before)
 #pragma unroll
           for (int v = 0; v < kInvPer; ++v)
@@ -332,17 +453,9 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
           if (p < seg.count) {
             const uint64_t k2 = kp[p];
             in_run = inv_term(k2) == t;
-            // a row that lists a term twice (caller-supplied vectors may) has equal keys side by side, in the row's
-            // own order (the sort is stable): the first of the run adds them all, one after the other
-            if (in_run && !(p > 0 && kp[p - 1] == k2)) {
+            if (in_run) {
               const int r = static_cast<int>(k2 & (kInvSegRows - 1));
-              float acc = score[r];
-              int q = p;
-              do {
-                acc = __fadd_rn(acc, __fmul_rn(w, vp[q]));
-                ++q;
-              } while (q < seg.count && kp[q] == k2);
-              score[r] = acc;
+              score[r] = __fadd_rn(score[r], __fmul_rn(w, vp[p]));
               hit[r] = 1;
             }
           }
