@@ -231,6 +231,7 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     std::swap(e->inv_used, t.inv_used);
     std::swap(e->n_inv_seg, t.n_inv_seg);
     std::swap(e->inv_slices, t.inv_slices);
+    std::swap(e->inv_rows, t.inv_rows);
     e->n_slices_dev = t.n_slices_dev;
     e->sp_used = t.sp_used;
     e->cap_rows = t.cap_rows;
