@@ -268,6 +268,7 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
 #define VR_STAT_LAST_CANDIDATES 2  /* rows re-scored by the last two-stage search */
 #define VR_STAT_BATCHED 3          /* queries served by the batched (integer GEMM) dense search */
 #define VR_STAT_BATCH_FALLBACK 4   /* ... of which exceeded their candidate budget and were redone alone */
+#define VR_STAT_BATCH_CANDIDATES 6 /* rows re-scored exactly by the batched search, summed over its queries */
 #define VR_STAT_GENERATION 5       /* bumped whenever row numbers change meaning (vr_compact, vr_load): a host
                                       table keyed by row is valid for the generation it was built against */
 int vr_stats(vr_engine* e, int32_t which, int64_t* out);

@@ -292,6 +292,7 @@ struct SearchLane {
     m->stat_fallback += L->stat_fallback.exchange(0);
     m->stat_batched += L->stat_batched.exchange(0);
     m->stat_batch_fallback += L->stat_batch_fallback.exchange(0);
+    m->stat_batch_cands += L->stat_batch_cands.exchange(0);
     const int64_t lc = L->stat_last_candidates.exchange(-1);
     if (lc >= 0) m->stat_last_candidates.store(lc);
     if (lock.owns_lock()) lock.unlock();
@@ -690,6 +691,7 @@ int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
     case VR_STAT_LAST_CANDIDATES: *out = e->stat_last_candidates.load(); break;
     case VR_STAT_BATCHED: *out = e->stat_batched.load(); break;
     case VR_STAT_BATCH_FALLBACK: *out = e->stat_batch_fallback.load(); break;
+    case VR_STAT_BATCH_CANDIDATES: *out = e->stat_batch_cands.load(); break;
     case VR_STAT_GENERATION: *out = e->generation.load(); break;
     default: set_error("unknown statistic %d", which); return -1;
   }
@@ -801,8 +803,9 @@ static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int me
       VR_HIP(hipMemcpyAsync(over.data(), over_dev, sizeof(int32_t) * static_cast<size_t>(nb), hipMemcpyDeviceToHost, e->stream));
       VR_HIP(hipStreamSynchronize(e->stream));
       e->stat_batched += nb;
+      for (int i = 0; i < nb; ++i) e->stat_batch_cands += std::min<int32_t>(over[static_cast<size_t>(i)], kBatchCand);
       for (int i = 0; i < nb; ++i)
-        if (over[static_cast<size_t>(i)]) {  // candidate budget exceeded: this query alone, through the exact scans
+        if (over[static_cast<size_t>(i)] > kBatchCand) {  // candidate budget exceeded: this query alone, through the exact scans
           ++e->stat_batch_fallback;
           VR_TRY(run_block(q + static_cast<int64_t>(q0 + i) * e->dim, 1, q0 + i));
         }

@@ -42,7 +42,6 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 constexpr int kBQ = 128;          // queries per block column
 constexpr int kBStage = 64 * 1024;  // bytes per stage: 16 tiles x 2 kb8 KiB of rows + 8 qfrags x {a,b} x 2 kb8 KiB
-constexpr int kBatchCand = 1024;  // candidate budget per query
 constexpr int kQParams = 8;       // floats per query: a, b, |q|, |rho|, c_fixed, (3 spare)
 
 // ---- prep ---------------------------------------------------------------------------------------------
@@ -147,15 +146,16 @@ template <int PASS>
 __global__ __launch_bounds__(512) void batch_scan_kernel(
     const uint4* __restrict__ corpus8, const uint4* __restrict__ img_a, const uint4* __restrict__ img_b,
     const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
-    const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int n_qc, int nq, int kb8n,
+    const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int rb_stride, int n_qc, int nq, int kb8n,
     float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt) {
   __shared__ uint4 lds[2 * kBStage / 16];  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
   // blocks b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart
   const int bid = blockIdx.x;
   const int lane8 = bid & 7, rest = bid >> 3;
   const int qc = rest % n_qc;
-  const int rb = (rest / n_qc) * 8 + lane8;
-  if (rb >= n_rb) return;  // block-uniform
+  const int rbi = (rest / n_qc) * 8 + lane8;  // n_rb row blocks in the grid: every rb_stride-th of the corpus (pass 1 samples)
+  if (rbi >= n_rb) return;  // block-uniform
+  const int rb = rbi * rb_stride;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -184,6 +184,21 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     glds16b(gBb + k0, d + (32 + 4 * wave + 2) * 64);
     glds16b(gBb + k0 + 64, d + (32 + 4 * wave + 3) * 64);
   };
+
+  // the constants of this lane's two queries (needed by the epilogue only; requested now, so that they are there)
+  float pa[2], pb[2], pqn[2], prho[2], pcf[2], pthr[2];
+  int qidx[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
+    const float* p = params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams;
+    pa[f] = p[0];
+    pb[f] = p[1];
+    pqn[f] = p[2];
+    prho[f] = p[3];
+    pcf[f] = p[4];
+    pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
+  }
 
   i32x4 acc[8][2][2];  // [row tile of the wave][qfrag of the wave][part a, b]
 #pragma unroll
@@ -220,33 +235,29 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     __syncthreads();
   }
 
-  // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile
+  // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile.
+  // The per-row words of all eight tiles are requested together (clamped addresses, so nothing depends on the
+  // tail test): as a loop with a break in it they were eight round trips to memory, one after the other.
   const int g = lane >> 4;
-  float pa[2], pb[2], pqn[2], prho[2], pcf[2], pthr[2], run[2];
-  int qidx[2];
+  uchar4 m8[8];
+  float4 e8[8], s8[8];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
-    const float* p = params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams;
-    pa[f] = p[0];
-    pb[f] = p[1];
-    pqn[f] = p[2];
-    prho[f] = p[3];
-    pcf[f] = p[4];
-    pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
-    run[f] = -__builtin_inff();
+  for (int i = 0; i < 8; ++i) {
+    const int64_t tile = std::min<int64_t>(tile0 + 8 * wm + i, last_tile);
+    const int64_t row0 = tile * kTileRows + 4 * g;
+    m8[i] = *reinterpret_cast<const uchar4*>(mask + row0);
+    e8[i] = *reinterpret_cast<const float4*>(row_err + row0);
+    s8[i] = *reinterpret_cast<const float4*>(row_scale + row0);
   }
+  float run[2] = {-__builtin_inff(), -__builtin_inff()};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t tile = tile0 + 8 * wm + i;
-    if (tile > last_tile) break;  // wave-uniform
+    const bool real = tile <= last_tile;  // wave-uniform
     const int64_t row0 = tile * kTileRows + 4 * g;
-    const uchar4 m = *reinterpret_cast<const uchar4*>(mask + row0);
-    const float4 e4 = *reinterpret_cast<const float4*>(row_err + row0);
-    const float4 s4 = *reinterpret_cast<const float4*>(row_scale + row0);
-    const unsigned char mm[4] = {m.x, m.y, m.z, m.w};
-    const float ee[4] = {e4.x, e4.y, e4.z, e4.w};
-    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+    const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
+    const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
+    const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -257,8 +268,8 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
         const float score = ss[r] * (fa + fb);
         const float err = ee[r] * pqn[f] + (1.001f + ee[r]) * prho[f] + pcf[f] + 2.0e-6f * ss[r] * (fabsf(fa) + fabsf(fb));
         if (PASS == 1) {
-          if (mm[r]) run[f] = fmaxf(run[f], score - err);
-        } else if (mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
+          if (real && mm[r]) run[f] = fmaxf(run[f], score - err);
+        } else if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
           const int slot = atomicAdd(cand_cnt + qidx[f], 1);
           if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
         }
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
       float v = run[f];
       v = fmaxf(v, __shfl_xor(v, 16));
       v = fmaxf(v, __shfl_xor(v, 32));
-      if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rb + wm] = v;
+      if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rbi + wm] = v;
     }
   }
 }
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(256) void batch_final_kernel(const uint64_t* __rest
     v[i] = keys[static_cast<int64_t>(q) * kBatchCand + i * 256 + threadIdx.x];
     lmax = v[i] > lmax ? v[i] : lmax;
   }
-  if (threadIdx.x == 0) overflow[q] = cand_cnt[q] > kBatchCand;
+  if (threadIdx.x == 0) overflow[q] = cand_cnt[q];  // (the host compares it with the budget)
   for (int r = 0; r < k; ++r) {
     uint64_t m = lmax;
 #pragma unroll
@@ -406,19 +417,29 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
                      s, q_dev, nq, dim, kb8n, e->bq_hat.p, img_a, img_b, e->bq_params.p,
                      e->centre_rows > 0 ? e->centre_norm : 0.0f);
   const unsigned grid = static_cast<unsigned>(((n_rb + 7) / 8) * n_qc * 8);
+  // Pass 1 only has to produce SOME k rows' lower bounds per query, so it could run on every stride-th row block
+  // (VR_BATCH_SAMPLE=stride; at least 8 k slabs, and 64, stay in the sample). Measured and NOT the default: the
+  // threshold of a sample is lower, and the candidate count is steep in it — bench corpus, 1000 queries: 69
+  // candidates per query with the full pass, 239 at stride 4 (scan 5.3 -> 3.5 ms, call 6.9 -> 6.7 ms: the exact
+  // re-score eats the gain), 800 at stride 16 with a fifth of the queries over budget; an anisotropic corpus
+  // overflows at stride 4 already (profiles/r02_gemm_experiments.md §11).
+  static const int want_stride = getenv("VR_BATCH_SAMPLE") ? std::max(1, atoi(getenv("VR_BATCH_SAMPLE"))) : 1;
+  const int stride = std::max(1, std::min(want_stride, 2 * n_rb / std::max(8 * k, 64)));
+  const int n_rb1 = (n_rb + stride - 1) / stride;
+  const unsigned grid1 = static_cast<unsigned>(((n_rb1 + 7) / 8) * n_qc * 8);
   // algorithmic work of the batched scan: 2 N D Q operations (the second pass and the second query part are overhead)
   prof_begin(e, VR_PROF_BATCH_SCAN, 2.0 * static_cast<double>(e->n_rows) * dim * nq);
-  hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+  hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid1), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                      reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
-                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, n_qc, nq, kb8n, e->bq_best.p,
+                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb1, stride, n_qc, nq, kb8n, e->bq_best.p,
                      static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
   const uint64_t* kth = nullptr;
-  VR_TRY(topk_select(e, e->bq_best.p, 2 * n_rb, 2 * n_rb, nq, k, &kth));
+  VR_TRY(topk_select(e, e->bq_best.p, 2 * n_rb1, 2 * n_rb1, nq, k, &kth));
   hipLaunchKernelGGL(batch_threshold_kernel, dim3(static_cast<unsigned>((nq + 255) / 256)), dim3(256), 0, s, kth, nq, k,
                      e->bq_thr.p);
   hipLaunchKernelGGL((batch_scan_kernel<2>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                      reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
-                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, n_qc, nq, kb8n, static_cast<float*>(nullptr),
+                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, 1, n_qc, nq, kb8n, static_cast<float*>(nullptr),
                      e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p);
   prof_end(e);
   uint64_t* keys = e->bq_keys.p;

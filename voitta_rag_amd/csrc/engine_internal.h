@@ -94,6 +94,7 @@ struct InvSeg {
   int32_t nrows;
   int32_t pad;
 };
+constexpr int kBatchCand = 1024;   // candidate budget per query of the batched dense search (batch.hip)
 constexpr int kInvRowBits = 12;
 constexpr int kInvSegRows = 1 << kInvRowBits;
 constexpr int kInvSubShift = 43;
@@ -188,6 +189,7 @@ struct vr_engine {
   std::atomic<int64_t> stat_two_stage{0};       // single-query dense searches served by the two-stage path
   std::atomic<int64_t> stat_fallback{0};        // ... of which overflowed the re-score budget and were redone one-stage
   std::atomic<int64_t> stat_batched{0};         // queries served by the batched search (batch.hip)
+  std::atomic<int64_t> stat_batch_cands{0};     // ... and the rows they re-scored exactly, in total
   std::atomic<int64_t> stat_batch_fallback{0};  // ... of which overflowed their candidate budget and were redone alone
   std::atomic<int64_t> stat_last_candidates{0}; // rows re-scored by the last two-stage search
   std::atomic<int64_t> generation{0};           // bumped whenever row numbers change (vr_compact's swap, vr_load)
