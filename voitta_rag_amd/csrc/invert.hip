@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void inv_emit_kernel(const SliceDesc* __restric
 
 // The sort of a batch's postings by key: a bitonic network over the batch padded to a power of two with keys of all
 // ones. Data independent (caller-supplied term ids are not hashes), in place, and off every latency path: a batch of
-// 2200 chunks (88k postings) is 21 small launches, a million rows (40M) about a hundred passes over 0.8 GB. Equal
+// 2200 chunks (88k postings) is 15 small launches, a million rows (40M) about sixty passes over 0.8 GB. Equal
 // keys (a row that lists a term twice) may change places — such collections do not use this index (sp_has_dups).
 constexpr int kSortTile = 4096;     // postings a block sorts in LDS (48 KiB)
 constexpr int kSortThreads = 1024;
@@ -156,12 +156,54 @@ __global__ __launch_bounds__(256) void bitonic_global_kernel(uint64_t* __restric
   }
 }
 
+// two passes of stage `size` in one: strides `stride` and `stride / 2` (both at least the tile size). A thread owns
+// the four postings that differ in those two index bits, which is all either pass touches of them.
+__global__ __launch_bounds__(256) void bitonic_global2_kernel(uint64_t* __restrict__ keys, float* __restrict__ vals,
+                                                              int64_t quarter, int64_t size, int64_t stride) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= quarter) return;
+  const int64_t lo = stride >> 1;
+  const int64_t i = ((t & ~(lo - 1)) << 2) | (t & (lo - 1));
+  const bool asc = (i & size) == 0;
+  const int64_t at[4] = {i, i + lo, i + stride, i + stride + lo};
+  uint64_t k[4];
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    k[j] = keys[at[j]];
+    v[j] = vals[at[j]];
+  }
+  auto cx = [&](int a, int b) {
+    if ((k[a] > k[b]) == asc) {
+      const uint64_t tk = k[a];
+      k[a] = k[b];
+      k[b] = tk;
+      const float tv = v[a];
+      v[a] = v[b];
+      v[b] = tv;
+    }
+  };
+  cx(0, 2);
+  cx(1, 3);
+  cx(0, 1);
+  cx(2, 3);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    keys[at[j]] = k[j];
+    vals[at[j]] = v[j];
+  }
+}
+
 static int inv_sort(vr_engine* e, uint64_t* keys, float* vals, int64_t n_pad) {
   const unsigned tiles = static_cast<unsigned>(n_pad / kSortTile);
   hipLaunchKernelGGL((bitonic_tile_kernel<true>), dim3(tiles), dim3(kSortThreads), 0, e->stream, keys, vals,
                      static_cast<int64_t>(0));
   for (int64_t size = 2 * kSortTile; size <= n_pad; size <<= 1) {
-    for (int64_t stride = size >> 1; stride >= kSortTile; stride >>= 1)
+    int64_t stride = size >> 1;
+    for (; (stride >> 1) >= kSortTile; stride >>= 2)
+      hipLaunchKernelGGL(bitonic_global2_kernel, dim3(static_cast<unsigned>((n_pad / 4 + 255) / 256)), dim3(256), 0,
+                         e->stream, keys, vals, n_pad / 4, size, stride);
+    if (stride >= kSortTile)
       hipLaunchKernelGGL(bitonic_global_kernel, dim3(static_cast<unsigned>((n_pad / 2 + 255) / 256)), dim3(256), 0,
                          e->stream, keys, vals, n_pad / 2, size, stride);
     hipLaunchKernelGGL((bitonic_tile_kernel<false>), dim3(tiles), dim3(kSortThreads), 0, e->stream, keys, vals, size);
