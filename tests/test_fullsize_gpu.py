@@ -123,6 +123,49 @@ def test_deletes_at_full_size(corpus):
     assert two.count() == (N, N - 5)
 
 
+def test_inverted_and_forward_sparse_scans_agree_at_full_size(corpus, monkeypatch):
+    """Two independent code paths for the sparse leg — the postings of the query's terms (csrc/invert.hip, what runs
+    by default) and the scan of every stored id (csrc/sparse.hip) — must return the same rows and the same f32 bits
+    over 1M rows x 24 terms, alone and inside a hybrid search (both fusion modes), before and after deletes."""
+    from voitta_rag_amd.engine import VR_FUSION_RRF
+
+    two, one, halves, q, keep = corpus
+    rng = np.random.default_rng(31)
+
+    def both(fn):
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+        a = fn()
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "0")
+        b = fn()
+        monkeypatch.setenv("VR_SPARSE_INVERTED", "1")
+        return a, b
+
+    def check():
+        for trial in range(12):
+            m = int(rng.integers(1, 9)) if trial < 10 else 32
+            slot = rng.choice(24, size=min(m, 24), replace=False)
+            base = (rng.random(len(slot)) ** 2 * 50_000).astype(np.int64)            # the corpus's own id distribution
+            if m == 32:                                                              # the most terms the postings serve
+                slot = np.concatenate([slot, rng.choice(24, size=8)])
+                base = np.concatenate([base, rng.integers(0, 50_000, size=8)])
+            qi = np.unique((base * 32 + slot).astype(np.int32))
+            qv = rng.uniform(0.5, 1.5, size=len(qi)).astype(np.float32)
+            for k in (10, 30, 64):
+                (ri, si), (rf, sf) = both(lambda: two.search_sparse(qi, qv, k))
+                assert np.array_equal(ri, rf) and np.array_equal(si.view(np.uint32), sf.view(np.uint32)), (trial, k)
+                assert np.all(si[:-1] >= si[1:])
+            for fusion in (None, VR_FUSION_RRF):
+                kw = {} if fusion is None else {"fusion": fusion}
+                a, b = both(lambda: two.search_hybrid(q[trial], qi, qv, 10, 0.3, **kw))
+                assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and a[2].tolist() == b[2].tolist()
+
+    check()
+    r, _ = two.search_sparse(np.asarray([3 * 32 + 0, 100 * 32 + 1], np.int32), np.ones(2, np.float32), 30)
+    two.delete_rows(r[:10])
+    one.delete_rows(r[:10])   # (the two engines of the fixture stay the same collection)
+    check()
+
+
 def test_batched_queries_equal_single_queries_at_full_size(corpus):
     """configs[4]'s query side on one shard: 1000 queries in ONE call (integer-GEMM batched search) must return, for
     every query, exactly what 1000 single searches return (two-stage single-query path), and both must agree with the
