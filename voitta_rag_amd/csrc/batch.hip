@@ -250,6 +250,16 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     s8[i] = *reinterpret_cast<const float4*>(row_scale + row0);
   }
   float run[2] = {-__builtin_inff(), -__builtin_inff()};
+  // The certain bound of prefilter_scan8_kernel, E = e_r |q| + (1.001 + e_r) |rho| + c_fixed + 2e-6 s_r (|fa| + |fb|),
+  // regrouped per query as e_r P1 + P2 + ... with P1 = |q| + |rho|, P2 = 1.001 |rho| + c_fixed (both rounded UP by
+  // three ulps, which covers the two fused operations that replace five): 64 (row, query) elements per lane and tile
+  // make the epilogue a third of the VALU work of this kernel, and nothing hides it.
+  float p1[2], p2[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    p1[f] = (pqn[f] + prho[f]) * 1.0000004f;
+    p2[f] = (1.001f * prho[f] + pcf[f]) * 1.0000004f;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t tile = tile0 + 8 * wm + i;
@@ -258,15 +268,15 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
     const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
     const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
+    const float c2[4] = {2.0e-6f * ss[0], 2.0e-6f * ss[1], 2.0e-6f * ss[2], 2.0e-6f * ss[3]};
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // exactly prefilter_scan8_kernel's arithmetic
         const float fa = pa[f] * static_cast<float>(acc[i][f][0][r]);
         const float fb = pb[f] * static_cast<float>(acc[i][f][1][r]);
         const float score = ss[r] * (fa + fb);
-        const float err = ee[r] * pqn[f] + (1.001f + ee[r]) * prho[f] + pcf[f] + 2.0e-6f * ss[r] * (fabsf(fa) + fabsf(fb));
+        const float err = fmaf(c2[r], fabsf(fa) + fabsf(fb), fmaf(ee[r], p1[f], p2[f]));
         if (PASS == 1) {
           if (real && mm[r]) run[f] = fmaxf(run[f], score - err);
         } else if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
