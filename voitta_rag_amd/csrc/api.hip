@@ -167,6 +167,8 @@ static void release_scratch(vr_engine* e) {
   e->bq_cand.release();
   e->bq_cnt.release();
   e->bq_keys.release();
+  e->bq_tile_ub.release();
+  e->bq_pairs.release();
   e->bq_stage.release();
   if (e->pinned) (void)hipHostFree(e->pinned);
   e->pinned = nullptr;

@@ -36,6 +36,8 @@
 #include <algorithm>
 #include <cfloat>
 
+#include <hip/hip_fp16.h>
+
 namespace vr {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
@@ -134,6 +136,25 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict
 
 // ---- scan ---------------------------------------------------------------------------------------------
 
+// The approximate score of one (row, query) from its two exact int32 dot products, and the CERTAIN bound on its
+// distance from the exact score: prefilter_scan8_kernel's E = e_r |q| + (1.001 + e_r) |rho| + c_fixed + 2e-6 s_r (|fa| + |fb|),
+// regrouped per query as e_r P1 + P2 + ... with P1 = |q| + |rho|, P2 = 1.001 |rho| + c_fixed (both rounded UP by three
+// ulps, which covers the two fused operations that replace five). One function, so that the scan and the revisit of
+// the flagged tiles (batch_pairs_kernel) compute the same bits.
+__device__ __forceinline__ void batch_query_consts(const float* __restrict__ p, float& pa, float& pb, float& p1, float& p2) {
+  pa = p[0];
+  pb = p[1];
+  p1 = (p[2] + p[3]) * 1.0000004f;
+  p2 = (1.001f * p[3] + p[4]) * 1.0000004f;
+}
+__device__ __forceinline__ void batch_bound(float pa, float pb, float p1, float p2, float ss, float ee, int dot_a, int dot_b,
+                                            float& score, float& err) {
+  const float fa = pa * static_cast<float>(dot_a);
+  const float fb = pb * static_cast<float>(dot_b);
+  score = ss * (fa + fb);
+  err = fmaf(2.0e-6f * ss, fabsf(fa) + fabsf(fb), fmaf(ee, p1, p2));
+}
+
 __device__ __forceinline__ void glds16b(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -147,7 +168,8 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     const uint4* __restrict__ corpus8, const uint4* __restrict__ img_a, const uint4* __restrict__ img_b,
     const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
     const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int rb_stride, int n_qc, int nq, int kb8n,
-    float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt) {
+    float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt,
+    __half* __restrict__ tile_ub) {
   __shared__ uint4 lds[2 * kBStage / 16];  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
   // blocks b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart
   const int bid = blockIdx.x;
@@ -186,17 +208,12 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
   };
 
   // the constants of this lane's two queries (needed by the epilogue only; requested now, so that they are there)
-  float pa[2], pb[2], pqn[2], prho[2], pcf[2], pthr[2];
+  float pa[2], pb[2], p1[2], p2[2], pthr[2];
   int qidx[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
-    const float* p = params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams;
-    pa[f] = p[0];
-    pb[f] = p[1];
-    pqn[f] = p[2];
-    prho[f] = p[3];
-    pcf[f] = p[4];
+    batch_query_consts(params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams, pa[f], pb[f], p1[f], p2[f]);
     pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
   }
 
@@ -250,16 +267,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     s8[i] = *reinterpret_cast<const float4*>(row_scale + row0);
   }
   float run[2] = {-__builtin_inff(), -__builtin_inff()};
-  // The certain bound of prefilter_scan8_kernel, E = e_r |q| + (1.001 + e_r) |rho| + c_fixed + 2e-6 s_r (|fa| + |fb|),
-  // regrouped per query as e_r P1 + P2 + ... with P1 = |q| + |rho|, P2 = 1.001 |rho| + c_fixed (both rounded UP by
-  // three ulps, which covers the two fused operations that replace five): 64 (row, query) elements per lane and tile
-  // make the epilogue a third of the VALU work of this kernel, and nothing hides it.
-  float p1[2], p2[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    p1[f] = (pqn[f] + prho[f]) * 1.0000004f;
-    p2[f] = (1.001f * prho[f] + pcf[f]) * 1.0000004f;
-  }
+  const int nq_pad = n_qc * kBQ;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t tile = tile0 + 8 * wm + i;
@@ -268,22 +276,43 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
     const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
     const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
-    const float c2[4] = {2.0e-6f * ss[0], 2.0e-6f * ss[1], 2.0e-6f * ss[2], 2.0e-6f * ss[3]};
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 2; ++f) {
+      float top = -__builtin_inff();  // PASS 1: the largest upper bound among this lane's four rows of the tile
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float fa = pa[f] * static_cast<float>(acc[i][f][0][r]);
-        const float fb = pb[f] * static_cast<float>(acc[i][f][1][r]);
-        const float score = ss[r] * (fa + fb);
-        const float err = fmaf(c2[r], fabsf(fa) + fabsf(fb), fmaf(ee[r], p1[f], p2[f]));
+        float score, err;
+        batch_bound(pa[f], pb[f], p1[f], p2[f], ss[r], ee[r], acc[i][f][0][r], acc[i][f][1][r], score, err);
         if (PASS == 1) {
-          if (real && mm[r]) run[f] = fmaxf(run[f], score - err);
+          if (real && mm[r]) {
+            run[f] = fmaxf(run[f], score - err);
+            top = fmaxf(top, score + err);
+          }
         } else if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
           const int slot = atomicAdd(cand_cnt + qidx[f], 1);
           if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
         }
       }
+      // the tile's 16 rows are spread over the four lane groups: each leaves its four-row maximum in LDS (free since
+      // the last K-tile's barrier) as [group][16 tiles][128 queries] f16 rounded up; they are folded on the way out
+      // (cross-lane maxima here — two swizzles per tile and fragment — cost pass 1 a sixth of its time, and so did
+      // writing the bounds as 2-byte stores from 16 lanes)
+      if (PASS == 1 && tile_ub)
+        reinterpret_cast<__half*>(lds)[((g * 16 + 8 * wm + i) * kBQ) + (2 * wn + f) * 16 + (lane & 15)] = __float2half_ru(top);
+    }
+  }
+  if (PASS == 1 && tile_ub) {
+    __syncthreads();
+    const int row = threadIdx.x >> 5, part = threadIdx.x & 31;  // 16 tiles x 32 pieces of four queries (8 bytes)
+    using h4 = __attribute__((ext_vector_type(4))) _Float16;
+    h4 best4 = reinterpret_cast<const h4*>(lds)[row * 32 + part];
+#pragma unroll
+    for (int gg = 1; gg < 4; ++gg) {
+      const h4 o = reinterpret_cast<const h4*>(lds)[(gg * 16 + row) * 32 + part];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) best4[j] = o[j] > best4[j] ? o[j] : best4[j];
+    }
+    *reinterpret_cast<h4*>(tile_ub + (tile0 + row) * nq_pad + qc * kBQ + part * 4) = best4;
   }
   if (PASS == 1) {
     // this wave's 128 rows -> one value per query (the four lane groups hold different rows of the same queries)
@@ -293,6 +322,94 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
       v = fmaxf(v, __shfl_xor(v, 16));
       v = fmaxf(v, __shfl_xor(v, 32));
       if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rbi + wm] = v;
+    }
+  }
+}
+
+// ---- instead of a second pass: revisit the few (tile, query) pairs that can hold a candidate ------------------
+//
+// Pass 1 leaves, beside the per-slab lower bounds, the largest UPPER bound of every (16-row tile, query) as an f16
+// rounded up (2 B x N/16 x Q: 131 MB for 1k queries over a million rows). A row can only be a candidate of query q
+// if its tile's bound reaches T_q, and there are about as many such pairs as candidates (tens per query), so the
+// second integer GEMM over the whole corpus is replaced by
+//   batch_flag_kernel   one compare per (tile, query) -> a list of pairs;
+//   batch_pairs_kernel  a wave per pair: the 16 rows' exact int32 dot products with the query's two int8 parts on
+//                       v_dot4_i32_i8 (lane = (row, 16-byte k segment), the shadow tile and the query image are read
+//                       in the layout the MFMAs read them), then batch_bound() — the same bits as pass 1 — and the
+//                       rows whose upper bound reaches T_q go to the query's candidate list, as pass 2 put them.
+
+__global__ __launch_bounds__(256) void batch_flag_kernel(const __half* __restrict__ tile_ub, const float* __restrict__ thr,
+                                                         int64_t n_cells, int nq, int nq_pad, int32_t* __restrict__ pairs,
+                                                         int32_t* __restrict__ pair_cnt, int32_t* __restrict__ cand_cnt) {
+  // eight cells (one tile, eight consecutive queries) per thread; hits are rare (about as many as candidates).
+  // The lists are per query: one list for all put every hit through ONE atomic counter (0.8 ms for 68k hits).
+  const int64_t cell0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 8;
+  if (cell0 >= n_cells) return;
+  const int q0 = static_cast<int>(cell0 % nq_pad);  // nq_pad % 128 == 0: the eight cells share the tile
+  const int64_t tile = cell0 / nq_pad;
+  const uint4 raw = *reinterpret_cast<const uint4*>(tile_ub + cell0);
+  const float4 t0 = *reinterpret_cast<const float4*>(thr + q0), t1 = *reinterpret_cast<const float4*>(thr + q0 + 4);  // thr is padded
+  const float tq[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float ub = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)));
+    const int q = q0 + j;
+    if (q < nq && ub >= tq[j]) {
+      const int slot = atomicAdd(pair_cnt + q, 1);
+      if (slot < kBatchCand) pairs[static_cast<int64_t>(q) * kBatchCand + slot] = static_cast<int32_t>(tile);
+      else if (slot == kBatchCand) atomicAdd(cand_cnt + q, kBatchCand + 1);  // more tiles than the budget of rows: redone alone
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void batch_pairs_kernel(
+    const uint4* __restrict__ corpus8, const uint4* __restrict__ img_a, const uint4* __restrict__ img_b,
+    const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
+    const uint8_t* __restrict__ mask, int64_t n_rows, int kb8n, const float* __restrict__ thr, int nq,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ pair_cnt, int32_t* __restrict__ cand,
+    int32_t* __restrict__ cand_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, ks = lane >> 4;  // the shadow's layout: lane = (k % 64) / 16 * 16 + row % 16, 16 bytes each
+  const int64_t waves = static_cast<int64_t>(gridDim.x) * 4;
+  const int wpq = static_cast<int>(waves / nq > 0 ? waves / nq : 1);  // waves that share a query's list
+  for (int64_t job = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); job < static_cast<int64_t>(nq) * wpq; job += waves) {
+    const int q = static_cast<int>(job / wpq);
+    const int n = min(pair_cnt[q], kBatchCand);
+    float pa, pb, p1, p2;
+    batch_query_consts(params + static_cast<int64_t>(q) * kQParams, pa, pb, p1, p2);
+    const float tq = thr[q];
+    // the query images: [qfrag][kb8][lane = (k % 64) / 16 * 16 + query % 16][16 bytes]
+    const uint4* qa = img_a + (static_cast<int64_t>(q >> 4) * kb8n) * 64 + ks * 16 + (q & 15);
+    const uint4* qb = img_b + (static_cast<int64_t>(q >> 4) * kb8n) * 64 + ks * 16 + (q & 15);
+    for (int sl = static_cast<int>(job % wpq); sl < n; sl += wpq) {
+      const int64_t tile = pairs[static_cast<int64_t>(q) * kBatchCand + sl];
+      const uint4* x = corpus8 + tile * kb8n * 64 + lane;
+      int da = 0, db = 0;
+      for (int kb = 0; kb < kb8n; ++kb) {
+        const uint4 xv = x[kb * 64], av = qa[kb * 64], bv = qb[kb * 64];
+        da = __builtin_amdgcn_sdot4(static_cast<int>(xv.x), static_cast<int>(av.x), da, false);
+        da = __builtin_amdgcn_sdot4(static_cast<int>(xv.y), static_cast<int>(av.y), da, false);
+        da = __builtin_amdgcn_sdot4(static_cast<int>(xv.z), static_cast<int>(av.z), da, false);
+        da = __builtin_amdgcn_sdot4(static_cast<int>(xv.w), static_cast<int>(av.w), da, false);
+        db = __builtin_amdgcn_sdot4(static_cast<int>(xv.x), static_cast<int>(bv.x), db, false);
+        db = __builtin_amdgcn_sdot4(static_cast<int>(xv.y), static_cast<int>(bv.y), db, false);
+        db = __builtin_amdgcn_sdot4(static_cast<int>(xv.z), static_cast<int>(bv.z), db, false);
+        db = __builtin_amdgcn_sdot4(static_cast<int>(xv.w), static_cast<int>(bv.w), db, false);
+      }
+      da += __shfl_xor(da, 16);
+      da += __shfl_xor(da, 32);
+      db += __shfl_xor(db, 16);
+      db += __shfl_xor(db, 32);
+      const int64_t row = tile * kTileRows + r;
+      if (ks == 0 && row < n_rows && mask[row]) {
+        float score, err;
+        batch_bound(pa, pb, p1, p2, row_scale[row], row_err[row], da, db, score, err);
+        if (score + err >= tq) {
+          const int slot = atomicAdd(cand_cnt + q, 1);
+          if (slot < kBatchCand) cand[static_cast<int64_t>(q) * kBatchCand + slot] = static_cast<int32_t>(row);
+        }
+      }
     }
   }
 }
@@ -415,7 +532,7 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   VR_TRY(e->bq_img.grow(2 * nq_pad * dim / 4, 0, s));  // two int8 images, counted in int32
   VR_TRY(e->bq_params.grow(static_cast<int64_t>(nq) * kQParams, 0, s));
   VR_TRY(e->bq_best.grow(static_cast<int64_t>(nq) * 2 * n_rb, 0, s));
-  VR_TRY(e->bq_thr.grow(nq, 0, s));
+  VR_TRY(e->bq_thr.grow(nq_pad, 0, s));  // (padded: batch_flag_kernel reads eight thresholds at a time)
   VR_TRY(e->bq_cand.grow(static_cast<int64_t>(nq) * kBatchCand, 0, s));
   VR_TRY(e->bq_cnt.grow(2 * static_cast<int64_t>(nq), 0, s));  // counts, then overflow flags
   VR_TRY(e->bq_keys.grow(static_cast<int64_t>(nq) * kBatchCand + static_cast<int64_t>(nq) * k, 0, s));
@@ -439,18 +556,40 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   const unsigned grid1 = static_cast<unsigned>(((n_rb1 + 7) / 8) * n_qc * 8);
   // algorithmic work of the batched scan: 2 N D Q operations (the second pass and the second query part are overhead)
   prof_begin(e, VR_PROF_BATCH_SCAN, 2.0 * static_cast<double>(e->n_rows) * dim * nq);
+  // VR_BATCH_TWO_PASS=1 (and a sampled pass 1) keeps the second integer GEMM; the default revisits flagged pairs
+  static const bool two_pass_env = getenv("VR_BATCH_TWO_PASS") && atoi(getenv("VR_BATCH_TWO_PASS")) != 0;
+  const bool two_pass = two_pass_env || stride != 1;
+  const int64_t n_cells = static_cast<int64_t>(n_rb) * 16 * nq_pad;  // (tile, query) cells, padded to whole blocks
+  const int64_t pair_cap = static_cast<int64_t>(nq) * kBatchCand;  // tiles listed per query, then the counts
+  __half* tile_ub = nullptr;
+  if (!two_pass) {
+    VR_TRY(e->bq_tile_ub.grow(n_cells, 0, s));
+    VR_TRY(e->bq_pairs.grow(pair_cap + nq, 0, s));
+    VR_HIP(hipMemsetAsync(e->bq_pairs.p + pair_cap, 0, sizeof(int32_t) * static_cast<size_t>(nq), s));
+    tile_ub = reinterpret_cast<__half*>(e->bq_tile_ub.p);
+  }
   hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid1), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                      reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                      e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb1, stride, n_qc, nq, kb8n, e->bq_best.p,
-                     static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
+                     static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                     tile_ub);
   const uint64_t* kth = nullptr;
   VR_TRY(topk_select(e, e->bq_best.p, 2 * n_rb1, 2 * n_rb1, nq, k, &kth));
   hipLaunchKernelGGL(batch_threshold_kernel, dim3(static_cast<unsigned>((nq + 255) / 256)), dim3(256), 0, s, kth, nq, k,
                      e->bq_thr.p);
-  hipLaunchKernelGGL((batch_scan_kernel<2>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
-                     reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
-                     e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, 1, n_qc, nq, kb8n, static_cast<float*>(nullptr),
-                     e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p);
+  if (two_pass) {
+    hipLaunchKernelGGL((batch_scan_kernel<2>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+                       reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
+                       e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, 1, n_qc, nq, kb8n, static_cast<float*>(nullptr),
+                       e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p, static_cast<__half*>(nullptr));
+  } else {
+    hipLaunchKernelGGL(batch_flag_kernel, dim3(static_cast<unsigned>((n_cells / 8 + 255) / 256)), dim3(256), 0, s, tile_ub,
+                       e->bq_thr.p, n_cells, nq, static_cast<int>(nq_pad), e->bq_pairs.p, e->bq_pairs.p + pair_cap, e->bq_cnt.p);
+    hipLaunchKernelGGL(batch_pairs_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+                       reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
+                       e->row_err.p, e->row_scale.p, mask_dev, e->n_rows, kb8n, e->bq_thr.p, nq, e->bq_pairs.p,
+                       e->bq_pairs.p + pair_cap, e->bq_cand.p, e->bq_cnt.p);
+  }
   prof_end(e);
   uint64_t* keys = e->bq_keys.p;
   uint64_t* out = keys + static_cast<int64_t>(nq) * kBatchCand;

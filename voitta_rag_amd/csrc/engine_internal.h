@@ -266,6 +266,8 @@ struct vr_engine {
   vr::DevArray<float> bq_hat, bq_params, bq_best, bq_thr;
   vr::DevArray<int32_t> bq_img, bq_cand, bq_cnt;
   vr::DevArray<uint64_t> bq_keys;
+  vr::DevArray<uint16_t> bq_tile_ub;  // f16 bits: per (16-row tile, query) the largest upper bound (rounded up)
+  vr::DevArray<int32_t> bq_pairs;     // per query: the tiles whose bound reaches its threshold ([nq][kBatchCand]), then the counts [nq]
   vr::DevArray<float> bq_stage;  // host queries staged on the device
   // Pinned, device-mapped host scratch (1 MiB). Query inputs are written here by the host and
   // read by the kernels straight over PCIe, results are written here by the last kernel of a
