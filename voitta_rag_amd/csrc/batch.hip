@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
 
 __global__ __launch_bounds__(256) void batch_flag_kernel(const __half* __restrict__ tile_ub, const float* __restrict__ thr,
                                                          int64_t n_cells, int nq, int nq_pad, int32_t* __restrict__ pairs,
-                                                         int32_t* __restrict__ pair_cnt, int32_t* __restrict__ cand_cnt) {
+                                                         int32_t* __restrict__ pair_cnt) {
   // eight cells (one tile, eight consecutive queries) per thread; hits are rare (about as many as candidates).
   // The lists are per query: one list for all put every hit through ONE atomic counter (0.8 ms for 68k hits).
   const int64_t cell0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 8;
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(256) void batch_flag_kernel(const __half* __restric
     const int q = q0 + j;
     if (q < nq && ub >= tq[j]) {
       const int slot = atomicAdd(pair_cnt + q, 1);
+      // (more tiles than the budget of rows: batch_final_kernel reports the query as overflowed and it is redone alone)
       if (slot < kBatchCand) pairs[static_cast<int64_t>(q) * kBatchCand + slot] = static_cast<int32_t>(tile);
-      else if (slot == kBatchCand) atomicAdd(cand_cnt + q, kBatchCand + 1);  // more tiles than the budget of rows: redone alone
     }
   }
 }
@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const float4* __rest
 // one block per query: the k best of its <= kBatchCand exact keys (k rounds of block-wide extract-max),
 // and the overflow flag for the host
 __global__ __launch_bounds__(256) void batch_final_kernel(const uint64_t* __restrict__ keys,
-                                                          const int32_t* __restrict__ cand_cnt, int k,
+                                                          const int32_t* __restrict__ cand_cnt,
+                                                          const int32_t* __restrict__ pair_cnt, int k,
                                                           uint64_t* __restrict__ out, int32_t* __restrict__ overflow) {
   __shared__ uint64_t wmax[2][4];
   const int q = blockIdx.x;
@@ -488,7 +489,8 @@ __global__ __launch_bounds__(256) void batch_final_kernel(const uint64_t* __rest
     v[i] = keys[static_cast<int64_t>(q) * kBatchCand + i * 256 + threadIdx.x];
     lmax = v[i] > lmax ? v[i] : lmax;
   }
-  if (threadIdx.x == 0) overflow[q] = cand_cnt[q];  // (the host compares it with the budget)
+  // (the host compares it with the budget; a query with more flagged tiles than the budget holds is over it as well)
+  if (threadIdx.x == 0) overflow[q] = (pair_cnt && pair_cnt[q] > kBatchCand) ? kBatchCand + 1 : cand_cnt[q];
   for (int r = 0; r < k; ++r) {
     uint64_t m = lmax;
 #pragma unroll
@@ -584,7 +586,7 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
                        e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p, static_cast<__half*>(nullptr));
   } else {
     hipLaunchKernelGGL(batch_flag_kernel, dim3(static_cast<unsigned>((n_cells / 8 + 255) / 256)), dim3(256), 0, s, tile_ub,
-                       e->bq_thr.p, n_cells, nq, static_cast<int>(nq_pad), e->bq_pairs.p, e->bq_pairs.p + pair_cap, e->bq_cnt.p);
+                       e->bq_thr.p, n_cells, nq, static_cast<int>(nq_pad), e->bq_pairs.p, e->bq_pairs.p + pair_cap);
     hipLaunchKernelGGL(batch_pairs_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                        reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                        e->row_err.p, e->row_scale.p, mask_dev, e->n_rows, kb8n, e->bq_thr.p, nq, e->bq_pairs.p,
@@ -596,8 +598,8 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   hipLaunchKernelGGL(batch_rescore_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(nq) * kBatchCand / 256)), dim3(256),
                      0, s, reinterpret_cast<const float4*>(e->corpus.p), e->bq_hat.p, e->bq_cand.p, e->bq_cnt.p, nq, dim,
                      e->kblocks, keys);
-  hipLaunchKernelGGL(batch_final_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, s, keys, e->bq_cnt.p, k, out,
-                     e->bq_cnt.p + nq);
+  hipLaunchKernelGGL(batch_final_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, s, keys, e->bq_cnt.p,
+                     two_pass ? static_cast<const int32_t*>(nullptr) : e->bq_pairs.p + pair_cap, k, out, e->bq_cnt.p + nq);
   VR_HIP(hipGetLastError());
   *out_keys_dev = out;
   *overflow_dev = e->bq_cnt.p + nq;
