@@ -705,8 +705,10 @@ def main():
                 else "forward SELL-64 scan",
             },
             "roofline_batched_search": {
-                "kernel": "vr::batch_scan_kernel<PASS> (v_mfma_i32_16x16x64_i8: int8 shadow corpus x int8 query parts, two passes: "
-                          "per-slab maxima for the thresholds, then candidates; exact f32 re-score of the candidates)",
+                "kernel": "vr::batch_scan_kernel<1> (v_mfma_i32_16x16x64_i8: int8 shadow corpus x int8 query parts -> per-slab lower "
+                          "bounds for the thresholds and an f16 upper bound per (16-row tile, query)) + batch_flag_kernel + "
+                          "batch_pairs_kernel (the few (tile, query) pairs that reach a threshold, on v_dot4_i32_i8); timed "
+                          "together; exact f32 re-score of the candidates follows",
                 "bound": "mfma",
                 "achieved": round(bscan_ops / (bscan_ms * 1e-3) / 1e12, 2) if bscan_ms > 0 else None,
                 "peak": 2 * PEAK_F16_MFMA_TFLOPS,

@@ -17,18 +17,23 @@
 //            conflict-free 16-byte fragment reads). The epilogue turns the two exact int32 dot products
 //            into the approximate score A = s_r (a dot_a + b dot_b) and the CERTAIN bound E of
 //            prefilter_scan8_kernel (residual norms by Cauchy-Schwarz; same formula, same constants).
-//            It runs twice:
-//              pass 1  per (128-row slab, query): the best LOWER bound A - E  ->  T_q = k-th largest of
-//                      them. Each is the lower bound of a different row, so at least k rows score >= T_q.
-//              pass 2  rows with A + E >= T_q are the candidates of query q (a superset of its top k).
-//            Two passes of integer MFMAs are cheaper than storing N x Q bounds (4 GB per 1k queries at 1M rows).
+//            Its epilogue leaves two things:
+//              per (128-row slab, query): the best LOWER bound A - E  ->  T_q = k-th largest of them. Each is the
+//                      lower bound of a different row, so at least k rows score >= T_q;
+//              per (16-row tile, query): the best UPPER bound A + E, as an f16 rounded up.
+//   revisit  rows with A + E >= T_q are the candidates of query q (a superset of its top k), and they can only sit in
+//            tiles whose stored bound reaches T_q: batch_flag_kernel lists those (tile, query) pairs — about as many as
+//            candidates, tens per query — and batch_pairs_kernel recomputes their 16 rows' bounds (v_dot4_i32_i8, the
+//            same bound function). Until r02j the GEMM simply ran a second time for this (VR_BATCH_TWO_PASS=1 still
+//            does): the revisit costs 0.25 ms where the second pass cost 2.4 (1k queries, a million rows). Storing all
+//            N x Q bounds instead would be 4 GB per 1k queries at 1M rows; one f16 per tile and query is 131 MB.
 //   rescore  every (query, candidate row) pair is scored with the exact k-ordered f32 fma chain (one lane per
 //            pair; the MFMA chain of dense.hip is bit for bit this chain) and ranked by the usual 64-bit keys.
 // A query whose candidates overflow its budget (a corpus of near-duplicates) is flagged; the host redoes
 // those with the one-stage 16-query scan, so the result never depends on the bound being tight.
 //
-// Roofline: int8 MFMA. Algorithmic work = 2 N D Q operations per pass that matters (SURVEY.md §8d counts the
-// dense top-k of Q batched queries as 2 N D Q); executed: 2 passes x 2 query parts = 4x that on the int8 pipe.
+// Roofline: int8 MFMA. Algorithmic work = 2 N D Q operations (SURVEY.md §8d counts the dense top-k of Q batched
+// queries as 2 N D Q); executed: 2 query parts = 2x that on the int8 pipe.
 
 #include "engine_internal.h"
 #include "topk_device.h"
@@ -556,7 +561,8 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   const int stride = std::max(1, std::min(want_stride, 2 * n_rb / std::max(8 * k, 64)));
   const int n_rb1 = (n_rb + stride - 1) / stride;
   const unsigned grid1 = static_cast<unsigned>(((n_rb1 + 7) / 8) * n_qc * 8);
-  // algorithmic work of the batched scan: 2 N D Q operations (the second pass and the second query part are overhead)
+  // algorithmic work of the batched scan: 2 N D Q operations (the second query part is overhead); timed: the GEMM
+  // pass, the threshold selection, and the flag + pairs kernels (or the second pass)
   prof_begin(e, VR_PROF_BATCH_SCAN, 2.0 * static_cast<double>(e->n_rows) * dim * nq);
   // VR_BATCH_TWO_PASS=1 (and a sampled pass 1) keeps the second integer GEMM; the default revisits flagged pairs
   static const bool two_pass_env = getenv("VR_BATCH_TWO_PASS") && atoi(getenv("VR_BATCH_TWO_PASS")) != 0;
