@@ -552,8 +552,7 @@ __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(const float4* 
   const int wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n_tiles > kMaxCandTiles ? 0x7fffffff : counter[1];
   if (threadIdx.x < kListLen) best[threadIdx.x] = 0ull;
-  if (q_resident)
-    for (int i = threadIdx.x; i < kblocks * 64; i += kRescoreThreads) stage[chunk * 64 + i] = q_img[i];
+  bool q_staged = !q_resident;  // a resident query image travels with the block's FIRST tile: one memory round trip, not two
   const bool active = (lane & 15) == 0;  // C/D map: column (query) = lane & 15; only query 0 exists
   for (int c = blockIdx.x; c < count; c += gridDim.x) {
     const int64_t tile = tiles[c];
@@ -567,8 +566,9 @@ __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(const float4* 
 #pragma unroll 4
       for (int i = threadIdx.x; i < nkb * 64; i += kRescoreThreads) {
         stage[i] = a_src[i];
-        if (!q_resident) stage[chunk * 64 + i] = b_src[i];
+        if (!q_staged || !q_resident) stage[chunk * 64 + i] = b_src[i];  // (resident: nkb == kblocks, b_src == q_img)
       }
+      q_staged = true;
       __syncthreads();
       if (wave == 0) {
 #pragma unroll 4
