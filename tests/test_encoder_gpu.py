@@ -216,3 +216,64 @@ def test_large_batches_fold_layernorm_into_the_gemms(gpu, name, layers, lens):
     got = _encode(shape, pooling, w, seqs, "f16")
     want = obert.sentence_embeddings(w, shape, seqs, pooling, True, np.float64)
     _check(got, want, f"{name} L{layers} folded GEMM LN, {sum(lens)} tokens", "f16")
+
+
+@pytest.mark.parametrize("name,layers,n_seq", [
+    ("bge-base-en-v1.5", 12, 2300),    # the bench's own step and a little more: 271k tokens = one full forward chunk + a tail
+    ("bge-large-en-v1.5", 24, 600),    # 70k tokens, 24 layers
+    ("all-MiniLM-L6-v2", 6, 800),      # 94k tokens; H = 384 (one and a half column tiles), mean pooling
+])
+def test_bench_scale_f16_path_against_the_f64_oracle(gpu, name, layers, n_seq):
+    """The code path bench.py times — the persistent 256x256 ping-pong GEMM walking many rounds of tiles per launch,
+    LayerNorm folded into the GEMMs (fold_big), the f16 residual stream, per-sequence attention, 262144-token
+    forward chunks — held to the f64 oracle AT ITS OWN SCALE. An embedding depends on its own sequence only, so a
+    sample is enough: first and last sequences, the ones whose rows straddle a 256-row tile edge, the ones on both
+    sides of the 262144-token chunk edge, and a spread in between (reference: embedding.py:56-74; north_star
+    tolerance 1e-4 on the cosine, held here to 1e-5)."""
+    base, pooling = obert.SHAPES[name]
+    shape = obert.BertShape(layers, base.hidden, base.heads, base.intermediate, vocab=1000, max_pos=base.max_pos)
+    w = obert.random_weights(shape, 31)
+    rng = np.random.default_rng(12)
+    lens = rng.integers(96, 141, size=n_seq)
+    seqs = [rng.integers(0, shape.vocab, size=int(n)).astype(np.int32) for n in lens]
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    total = int(cu[-1])
+    assert total > 65536
+    got = _encode(shape, pooling, w, seqs, "f16")
+    assert got.shape == (n_seq, shape.hidden) and np.all(np.isfinite(got))
+    pick = {0, 1, n_seq - 2, n_seq - 1}
+    # sequences whose rows cross a 256-row GEMM tile edge (the first few, one in the middle, the last)
+    crossing = [i for i in range(n_seq) if cu[i] // 256 != (cu[i + 1] - 1) // 256]
+    pick.update(crossing[:3] + crossing[len(crossing) // 2: len(crossing) // 2 + 2] + crossing[-3:])
+    if total > 262144:  # both sides of the forward-chunk edge (encoder.hip: kMaxChunkTokens)
+        edge = int(np.searchsorted(cu, 262144, side="right")) - 1  # first sequence of the second chunk
+        pick.update(range(max(edge - 2, 0), min(edge + 2, n_seq)))
+    want_n = 28 if layers <= 12 else 14
+    pick.update(int(i) for i in rng.choice(n_seq, size=max(want_n - len(pick), 0), replace=False))
+    pick = sorted(pick)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    want = obert.sentence_embeddings(w64, shape, [seqs[i] for i in pick], pooling, True, np.float64)
+    _check(got[pick], want, f"{name} L{layers} f16 at {total} tokens, {len(pick)} sampled sequences", "f16")
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+def test_f16_large_batch_rows_do_not_depend_on_their_place_in_the_batch(gpu):
+    """The f16 form of test_encode_is_batch_invariant_and_chunked: > 262144 tokens (several forward chunks) through
+    the large-batch kernels. A sequence's embedding must be the same BITS wherever it sits — other tile, other
+    round of the persistent walk, other forward chunk — because a GEMM row depends on its own row only (the K order
+    is the same for every row of every tile). The short-batch kernels differ by f16-level rounding, so the batch is
+    compared with a rotated copy of itself (and, to 1e-5 on the cosine, with each sampled sequence encoded alone)."""
+    base, pooling = obert.SHAPES["all-MiniLM-L6-v2"]
+    shape = obert.BertShape(2, base.hidden, base.heads, base.intermediate, vocab=500, max_pos=256)
+    w = obert.random_weights(shape, 3)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(1, 257, size=2200).tolist()
+    seqs = [rng.integers(0, shape.vocab, size=n).astype(np.int32) for n in lens]
+    assert sum(lens) > 262144
+    all_out = _encode(shape, pooling, w, seqs, "f16")
+    shift = 777
+    rotated = _encode(shape, pooling, w, seqs[shift:] + seqs[:shift], "f16")
+    assert np.array_equal(np.concatenate([rotated[-shift:], rotated[:-shift]]), all_out)
+    for i in (0, 57, 199, 399, 2199):
+        one = _encode(shape, pooling, w, [seqs[i]], "f16")
+        assert abs(1.0 - float((one[0] * all_out[i]).sum())) < 1e-5

@@ -228,3 +228,72 @@ def test_configs4_shard_batched_equals_single_queries_1p25m_x_1024(gpu):
         assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
     two.close()
     one.close()
+
+
+def test_configs3_shard_dense_only_1p25m_x_384(gpu):
+    """BASELINE configs[3], one rank's share: a 1.25M x 384 (MiniLM width) dense-only shard of the 10M corpus. The
+    two-stage search (int8 shadow) must equal the one-stage f32 scan bit for bit, the merge of two half shards must
+    equal the whole (what the RCCL top-k merge does), the winners' scores must be the oracle's fma chain on the rows
+    kept on the host, and a 1000-query batch must equal the single searches (reference: vector_store.py:612-617)."""
+    import torch
+
+    from voitta_rag_amd import Engine
+
+    n, d, blk = 1_250_000, 384, 125_000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(33)
+    two = Engine(d, initial_rows=n)
+    one = Engine(d, initial_rows=n, prefilter=False)
+    halves = [Engine(d, initial_rows=n // 2), Engine(d, initial_rows=n // 2, prefilter=False)]
+    keep = []
+    for a in range(0, n, blk):
+        x = torch.randn((blk, d), device=dev, generator=g)
+        x[:1000] = x[0] + 0.05 * torch.randn((1000, d), device=dev, generator=g)       # a cluster per block
+        for e in (two, one, halves[0] if a < n // 2 else halves[1]):
+            e.upsert(x.contiguous())
+        keep.append(x[:2000].cpu().numpy())
+    q = torch.randn((20, d), device=dev, generator=g)
+    q[:10] = torch.cat([torch.from_numpy(k[:1]) for k in keep]).to(dev) + 0.01 * torch.randn((10, d), device=dev, generator=g)
+    q = q.cpu().numpy()
+    assert two.count() == (n, n) and two.sparse_stats(np.asarray([1], np.int32))[1] == 0   # dense-only: no sparse points
+    for i in range(q.shape[0]):
+        for k in (10, 30):
+            r2, s2 = two.search_dense(q[i:i + 1], k)[0]
+            r1, s1 = one.search_dense(q[i:i + 1], k)[0]
+            assert np.array_equal(r2, r1) and np.array_equal(s2.view(np.uint32), s1.view(np.uint32)), (i, k)
+            assert len(set(r2.tolist())) == k and np.all(s2[:-1] >= s2[1:])
+            ties = s2[:-1] == s2[1:]
+            assert np.all(r2[:-1][ties] < r2[1:][ties])
+        # merge of the half shards = the whole
+        want_r, want_s = two.search_dense(q[i:i + 1], 30)[0]
+        parts = [h.search_dense(q[i:i + 1], 30)[0] for h in halves]
+        rows = np.concatenate([parts[0][0], parts[1][0] + n // 2])
+        scores = np.concatenate([parts[0][1], parts[1][1]])
+        order = np.lexsort((rows, -scores.astype(np.float64)))[:30]
+        assert np.array_equal(rows[order], want_r) and np.array_equal(scores[order], want_s)
+    st = two.stats()
+    assert st["two_stage"] >= q.shape[0] * 3 and st["fallback"] == 0
+    for b in range(10):  # winners against the oracle's arithmetic
+        rows, scores = two.search_dense(q[b:b + 1], 64)[0]
+        base = b * blk
+        local = (rows >= base) & (rows < base + 2000)
+        assert local.sum() >= 32
+        sc = ocore.dense_scores(ocore.cosine_preprocess(q[b:b + 1]), ocore.cosine_preprocess(keep[b]))[0]
+        assert np.array_equal(scores[local].view(np.uint32), sc[rows[local] - base].view(np.uint32))
+        outside = np.setdiff1d(np.arange(2000), rows[local] - base)
+        assert np.all(sc[outside] <= scores[-1])
+    # the batched form at this width (D = 384 = three 128-deep K-tiles of the integer GEMM)
+    rng = np.random.default_rng(6)
+    qs = rng.standard_normal((1000, d)).astype(np.float32)
+    qs[:20] = q
+    before = two.stats()
+    batched = two.search_dense(qs, 10)
+    assert two.stats()["batched"] - before["batched"] == 1000
+    for i in list(range(0, 1000, 9)) + list(range(20)):
+        r1, s1 = two.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+    for i in range(0, 20):
+        r1, s1 = one.search_dense(qs[i:i + 1], 10)[0]
+        assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
+    for e in (two, one, *halves):
+        e.close()
