@@ -336,6 +336,66 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem,
                      const vr_filter* filter,
                      int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count);
 
+/* ---- many queries per call (BASELINE configs[4]: 1k batched hybrid queries; the caller that would batch is the MCP
+ * search tool under load, mcp_server.py:469-485). The sparse queries of a batch are one CSR: query i's terms are
+ * q_idx / q_val [q_off[i], q_off[i + 1]) (host pointers). Results are, bit for bit, those of nq single calls. ---- */
+
+/* nq sparse queries (vector_store.py:647-656, once per query): rows[nq*k] (-1 padded), scores[nq*k], counts[nq].
+ * Queries of up to 32 distinct terms share ONE launch over the inverted index (csrc/invert.hip: grid = segment
+ * share x query); longer ones, k > 64 and collections kept on the forward scan are served one by one. */
+int vr_search_sparse_batch(vr_engine* e, const int64_t* q_off, const int32_t* q_idx, const float* q_val, int32_t nq,
+                           int32_t k, int32_t weights_given, const vr_filter* filter,
+                           int64_t* rows, float* scores, int32_t* counts);
+
+/* nq hybrid queries (_hybrid_search, vector_store.py:621-697, once per query): the dense legs as ONE batched dense
+ * search, the sparse legs as ONE batched sparse search beside it (second stream), the fusion of every query on the
+ * host threads. q: nq x D f32 (`mem`); sq_off may be NULL (no query has sparse terms).
+ * out_rows / out_scores / out_from_dense: nq x limit (entries beyond out_counts[i] are unspecified). */
+int vr_search_hybrid_batch(vr_engine* e, const float* q, int32_t nq, int mem,
+                           const int64_t* sq_off, const int32_t* sq_idx, const float* sq_val,
+                           int32_t limit, double sparse_weight, int32_t fusion, const vr_filter* filter,
+                           int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_counts);
+
+/* Both legs of nq hybrid queries as packed ranking keys (see vr_search_dense_keys), for a sharded caller: keys is
+ * [nq][2][k] uint64 in `keys_mem` memory — per query its dense list, then its sparse list. weights_given as in
+ * vr_search_sparse. The caller all-gathers the array, merges with vr_merge_keys and fuses with vr_fuse_batch
+ * (fusion runs on MERGED lists, never per shard: vector_store.py:659-689). */
+int vr_search_hybrid_keys(vr_engine* e, const float* q, int32_t nq, int mem,
+                          const int64_t* sq_off, const int32_t* sq_idx, const float* sq_val,
+                          int32_t k, int32_t weights_given, const vr_filter* filter, uint64_t* keys, int keys_mem);
+
+/* The per-shard top-k merge of SURVEY.md §8e on the engine's own kernel: parts is [n_parts][n_lists][k] keys (`mem`:
+ * the tensor an RCCL all_gather filled, or a host array), part p holding shard p's lists. Every list is merged over
+ * the parts — score descending, then lower local row, then lower part, i.e. ascending global id row * n_parts + p —
+ * into out_ids (global ids, -1 padded), out_scores and out_counts, host arrays [n_lists][k] / [n_lists].
+ * n_parts * k <= 4096. */
+int vr_merge_keys(vr_engine* e, const uint64_t* parts, int32_t n_parts, int32_t n_lists, int32_t k, int mem,
+                  int64_t* out_ids, float* out_scores, int32_t* out_counts);
+
+/* The fusion arithmetic for nq pairs of lists at once, on the host threads (vector_store.py:659-697 per query; the
+ * last step of a batched or sharded hybrid search). d_* / s_*: [nq][k] with counts [nq] (s_* may be NULL);
+ * out_*: [nq][limit], out_counts [nq]. fusion: VR_FUSION_*; json_scores as in vr_fuse_minmax. */
+int vr_fuse_batch(const int64_t* d_rows, const float* d_scores, const int32_t* d_counts,
+                  const int64_t* s_rows, const float* s_scores, const int32_t* s_counts,
+                  int32_t nq, int32_t k, int32_t limit, double sparse_weight, int32_t fusion, int32_t json_scores,
+                  int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_counts);
+
+/* ---- collection-wide document frequencies on a sharded corpus ("one all-reduce (sum) of df deltas
+ * after each upsert/delete batch"; Qdrant's Modifier.IDF statistic is collection-wide, vector_store.py:95-99).
+ * Every shard's table holds the statistic of ALL shards: after a shard stored (or before it deletes) rows, it exports
+ * their term ids, the shards exchange them (all_gather) and each applies the OTHERS' ids. A query then needs no
+ * exchange of statistics: one collective (the result merge) per hybrid query. -------------------------------------- */
+
+/* Term ids of the listed rows' sparse vectors in a fixed-stride layout: out[i * stride + j], -1 where row i has no
+ * j-th entry, is tombstoned or carries no sparse vector; out (`mem`, room for cap ids) may be NULL to ask for the
+ * stride alone. *stride = the widest stored sparse row; *n_points = listed rows that are live and carry a sparse
+ * vector. rows is a host array. */
+int vr_sparse_row_ids(vr_engine* e, const int64_t* rows, int64_t n, int32_t* out, int64_t cap, int mem,
+                      int32_t* stride, int64_t* n_points);
+/* df[id] += sign for every id >= 0 of ids (`mem`), sparse point count += sign * n_points: the statistics of rows
+ * that live on other shards. sign = +1 (stored there) or -1 (deleted there). */
+int vr_df_apply(vr_engine* e, const int32_t* ids, int64_t n_ids, int mem, int64_t n_points, int32_t sign);
+
 /* Persistence. The reference's index survives a restart in Qdrant's volume
  * (docker-compose.yml:8-9; VectorStoreService._ensure_collection re-attaches, vector_store.py:75-115).
  * vr_save writes everything the device owns — tiled dense corpus, payload columns, tombstones,

@@ -111,3 +111,24 @@ def sparse_scores(sparse_rows, q_idx, q_val, live=None) -> np.ndarray:
                                _p(qi, C.c_int32), _p(qv, C.c_float), len(qi), _p(qdf, C.c_int32),
                                n_points, _p(out, C.c_float))
     return out
+
+
+class SparseOracle:
+    """sparse_scores() for many queries over one collection state: the CSR form and the document frequencies
+    (Qdrant Modifier.IDF statistic over the LIVE points) are derived once."""
+
+    def __init__(self, sparse_rows, live=None):
+        self.rows = [r if r is not None else ([], []) for r in sparse_rows]
+        self.off, self.idx, self.val = to_csr(self.rows)
+        self.df, self.n_points = document_frequencies(sparse_rows, live)
+
+    def scores(self, q_idx, q_val) -> np.ndarray:
+        q = sorted({int(i): float(v) for i, v in reversed(list(zip(q_idx, q_val)))}.items())
+        qi = np.array([i for i, _ in q], dtype=np.int32)
+        qv = np.array([v for _, v in q], dtype=np.float32)
+        qdf = np.array([self.df.get(int(i), 0) for i in qi], dtype=np.int32)
+        out = np.empty(len(self.rows), dtype=np.float32)
+        lib().oracle_sparse_scores(_p(self.off, C.c_int64), _p(self.idx, C.c_int32), _p(self.val, C.c_float), len(self.rows),
+                                   _p(qi, C.c_int32), _p(qv, C.c_float), len(qi), _p(qdf, C.c_int32),
+                                   self.n_points, _p(out, C.c_float))
+        return out

@@ -125,6 +125,17 @@ SIGNATURES = {
     "vr_fuse_minmax": (C.c_int, [_i64p, _fp, C.c_int32, _i64p, _fp, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                  _i64p, _dp, _i32p, _i32p]),
     "vr_fuse_rrf": (C.c_int, [_i64p, C.c_int32, _i64p, C.c_int32, C.c_int32, _i64p, _dp, _i32p, _i32p]),
+    "vr_search_sparse_batch": (C.c_int, [_vp, _i64p, _i32p, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(VrFilter),
+                                         _i64p, _fp, _i32p]),
+    "vr_search_hybrid_batch": (C.c_int, [_vp, _vp, C.c_int32, C.c_int, _i64p, _i32p, _fp, C.c_int32, C.c_double,
+                                         C.c_int32, C.POINTER(VrFilter), _i64p, _dp, _i32p, _i32p]),
+    "vr_search_hybrid_keys": (C.c_int, [_vp, _vp, C.c_int32, C.c_int, _i64p, _i32p, _fp, C.c_int32, C.c_int32,
+                                        C.POINTER(VrFilter), _vp, C.c_int]),
+    "vr_merge_keys": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int, _i64p, _fp, _i32p]),
+    "vr_fuse_batch": (C.c_int, [_i64p, _fp, _i32p, _i64p, _fp, _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                C.c_int32, C.c_int32, _i64p, _dp, _i32p, _i32p]),
+    "vr_sparse_row_ids": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int64, C.c_int, _i32p, _i64p]),
+    "vr_df_apply": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int32]),
 }
 
 

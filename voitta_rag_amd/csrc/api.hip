@@ -9,6 +9,8 @@
 #include <climits>
 #include <thread>
 
+#include "host_parallel.h"
+
 namespace vr {
 
 static thread_local std::string g_last_error;
@@ -170,6 +172,15 @@ static void release_scratch(vr_engine* e) {
   e->bq_tile_ub.release();
   e->bq_pairs.release();
   e->bq_stage.release();
+  e->sq_off.release();
+  e->sq_ids.release();
+  e->sq_val.release();
+  e->sq_w.release();
+  e->sq_keys.release();
+  e->mg_in.release();
+  e->mg_gid.release();
+  e->mg_score.release();
+  e->mg_cnt.release();
   if (e->pinned) (void)hipHostFree(e->pinned);
   e->pinned = nullptr;
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -748,15 +759,15 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 // Dense search of nq queries; the nq x k ranking keys ((order-preserving f32 score bits << 32) | ~row, descending,
 // 0 = none) go to keys_host (host array) and/or keys_dev (device array). `e` is a search lane (SearchLane).
 static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int mem, int k, const vr_filter* filter,
-                                    uint64_t* keys_host, uint64_t* keys_dev) {
+                                    uint64_t* keys_host, uint64_t* keys_dev, const uint8_t* mask_in = nullptr) {
   const size_t row_bytes = sizeof(uint64_t) * static_cast<size_t>(k);
   if (e->n_rows == 0) {
     if (keys_host) memset(keys_host, 0, row_bytes * static_cast<size_t>(nq));
     if (keys_dev) VR_HIP(hipMemsetAsync(keys_dev, 0, row_bytes * static_cast<size_t>(nq), e->stream));
     return 0;
   }
-  const uint8_t* mask = nullptr;
-  VR_TRY(filter_build_mask(e, filter, &mask));
+  const uint8_t* mask = mask_in;
+  if (!mask) VR_TRY(filter_build_mask(e, filter, &mask));
   const uint64_t* pinned_keys = pin_host<uint64_t>(e, kPinDenseKeys);
   // one block of <= 16 queries through the one-/two-stage scans; its keys (in the pinned result area) go to slot `at`
   auto run_block = [&](const float* qsrc, int nb, int at) -> int {
@@ -978,6 +989,314 @@ int vr_fuse_rrf(const int64_t* d_rows, int32_t nd, const int64_t* s_rows, int32_
                 int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count) {
   VR_CHECK(nd >= 0 && ns >= 0 && out_rows && out_scores && out_count, "bad arguments");
   return fuse_rrf(d_rows, nd, s_rows, ns, limit, 0.0, out_rows, out_scores, out_from_dense, out_count);
+}
+
+}  // extern "C"
+
+// ---- many sparse / hybrid queries per call (BASELINE configs[4]: 1k batched hybrid queries) ------------------------
+
+namespace {
+
+// The sparse queries of a batch as the engine wants them: per query the terms in ascending id order, a repeated id
+// keeping its first value (what sparse_run does for one query; Qdrant sorts sparse vectors by index [EXT]).
+struct SparseBatch {
+  std::vector<int32_t> off;    // nq + 1: ranges of the queries the batch kernel serves (others: empty range)
+  std::vector<int32_t> ids;
+  std::vector<float> vals;
+  std::vector<int32_t> alone;  // queries it cannot serve (more than kInvMaxTerms distinct terms): one by one
+};
+
+int prepare_sparse_batch(const int64_t* q_off, const int32_t* q_idx, const float* q_val, int nq, bool batchable,
+                         SparseBatch* b) {
+  b->off.assign(static_cast<size_t>(nq) + 1, 0);
+  std::vector<std::pair<int32_t, float>> t;
+  for (int i = 0; i < nq; ++i) {
+    const int64_t lo = q_off[i], hi = q_off[i + 1];
+    VR_CHECK(hi >= lo && hi - lo <= kMaxQueryTerms, "sparse query %d has %lld terms (0..%d supported)", i,
+             static_cast<long long>(hi - lo), kMaxQueryTerms);
+    t.clear();
+    for (int64_t j = lo; j < hi; ++j) t.emplace_back(q_idx[j], q_val[j]);
+    std::stable_sort(t.begin(), t.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+    t.erase(std::unique(t.begin(), t.end(), [](const auto& a, const auto& c) { return a.first == c.first; }), t.end());
+    if (!t.empty() && (!batchable || static_cast<int>(t.size()) > kInvMaxTerms)) {
+      b->alone.push_back(i);
+    } else {
+      for (const auto& p : t) {
+        b->ids.push_back(p.first);
+        b->vals.push_back(p.second);
+      }
+    }
+    b->off[static_cast<size_t>(i) + 1] = static_cast<int32_t>(b->ids.size());
+  }
+  return 0;
+}
+
+// Queues the batch kernel of the prepared queries on e->stream; the nq x k keys end up in e->sq_keys (device).
+int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool weights_given, const uint8_t* mask) {
+  const int64_t nt = static_cast<int64_t>(b.ids.size());
+  VR_TRY(e->sq_off.grow(nq + 1, 0, e->stream));
+  VR_TRY(e->sq_ids.grow(std::max<int64_t>(nt, 1), 0, e->stream));
+  VR_TRY(e->sq_val.grow(std::max<int64_t>(nt, 1), 0, e->stream));
+  VR_TRY(e->sq_w.grow(std::max<int64_t>(nt, 1), 0, e->stream));
+  VR_TRY(e->sq_keys.grow(static_cast<int64_t>(nq) * k, 0, e->stream));
+  if (nt == 0 || e->n_rows == 0 || e->n_slices_dev == 0) {
+    VR_HIP(hipMemsetAsync(e->sq_keys.p, 0, sizeof(uint64_t) * static_cast<size_t>(nq) * k, e->stream));
+    return 0;
+  }
+  VR_HIP(hipMemcpyAsync(e->sq_off.p, b.off.data(), sizeof(int32_t) * (static_cast<size_t>(nq) + 1), hipMemcpyHostToDevice, e->stream));
+  VR_HIP(hipMemcpyAsync(e->sq_ids.p, b.ids.data(), sizeof(int32_t) * static_cast<size_t>(nt), hipMemcpyHostToDevice, e->stream));
+  VR_HIP(hipMemcpyAsync(e->sq_val.p, b.vals.data(), sizeof(float) * static_cast<size_t>(nt), hipMemcpyHostToDevice, e->stream));
+  return inv_scan_topk_batch(e, e->sq_off.p, e->sq_ids.p, e->sq_val.p, e->sq_w.p, nq, static_cast<int>(nt), weights_given,
+                             static_cast<float>(e->n_sparse_points), mask, k, e->sq_keys.p);
+}
+
+// The queries the batch kernel could not take, one at a time through the single-query scans (e->stream); their keys
+// replace row i of keys_host. q_off / q_idx / q_val: the caller's arrays.
+int sparse_batch_stragglers(vr_engine* e, const SparseBatch& b, const int64_t* q_off, const int32_t* q_idx, const float* q_val,
+                            int k, bool weights_given, const uint8_t* mask, uint64_t* keys_host) {
+  for (int32_t i : b.alone) {
+    const int nnz = static_cast<int>(q_off[i + 1] - q_off[i]);
+    uint64_t* dst = keys_host + static_cast<size_t>(i) * k;
+    if (e->n_rows == 0 || e->n_slices_dev == 0) {
+      memset(dst, 0, sizeof(uint64_t) * static_cast<size_t>(k));
+      continue;
+    }
+    VR_TRY(search_sparse_block(e, q_idx + q_off[i], q_val + q_off[i], nnz, k, mask, weights_given));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    memcpy(dst, pin_host<uint64_t>(e, kPinSparseKeys), sizeof(uint64_t) * static_cast<size_t>(k));
+  }
+  return 0;
+}
+
+// nq sparse searches -> nq x k keys in keys_host. `e` is a search lane; everything runs on e->stream.
+int search_sparse_keys_locked(vr_engine* e, const int64_t* q_off, const int32_t* q_idx, const float* q_val, int nq, int k,
+                              bool weights_given, const uint8_t* mask, uint64_t* keys_host) {
+  SparseBatch b;
+  VR_TRY(prepare_sparse_batch(q_off, q_idx, q_val, nq, k <= kFusedMaxK && inv_usable(e, 1), &b));
+  VR_TRY(sparse_batch_launch(e, b, nq, k, weights_given, mask));
+  VR_HIP(hipMemcpyAsync(keys_host, e->sq_keys.p, sizeof(uint64_t) * static_cast<size_t>(nq) * k, hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  return sparse_batch_stragglers(e, b, q_off, q_idx, q_val, k, weights_given, mask, keys_host);
+}
+
+// Both legs of nq hybrid queries: nq x k dense keys and nq x k sparse keys (host arrays). The sparse batch is queued
+// on the lane's auxiliary stream first and runs beside the dense batch (its kernels are small and latency-bound).
+int hybrid_keys_locked(vr_engine* e, const float* q, int nq, int mem, const int64_t* sq_off, const int32_t* sq_idx,
+                       const float* sq_val, int k, bool weights_given, const vr_filter* filter, uint64_t* dense_host,
+                       uint64_t* sparse_host) {
+  const size_t bytes = sizeof(uint64_t) * static_cast<size_t>(nq) * k;
+  if (e->n_rows == 0) {
+    memset(dense_host, 0, bytes);
+    memset(sparse_host, 0, bytes);
+    return 0;
+  }
+  const uint8_t* mask = nullptr;
+  VR_TRY(filter_build_mask(e, filter, &mask));
+  const bool have_sparse = sq_off != nullptr && sq_off[nq] > sq_off[0] && e->n_slices_dev > 0;
+  SparseBatch b;
+  if (have_sparse) {
+    VR_CHECK(sq_idx && sq_val, "null sparse queries");
+    VR_TRY(prepare_sparse_batch(sq_off, sq_idx, sq_val, nq, k <= kFusedMaxK && inv_usable(e, 1), &b));
+    VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask
+    VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+    hipStream_t main_stream = e->stream;
+    e->stream = e->aux_stream;
+    int rc = sparse_batch_launch(e, b, nq, k, weights_given, mask);
+    if (rc == 0 && hipMemcpyAsync(sparse_host, e->sq_keys.p, bytes, hipMemcpyDeviceToHost, e->stream) != hipSuccess) {
+      set_error("copying the sparse keys failed");
+      rc = -1;
+    }
+    e->stream = main_stream;
+    if (rc != 0) return rc;
+  } else {
+    memset(sparse_host, 0, bytes);
+  }
+  VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, dense_host, nullptr, mask));
+  if (have_sparse) {
+    VR_HIP(hipStreamSynchronize(e->aux_stream));
+    VR_TRY(sparse_batch_stragglers(e, b, sq_off, sq_idx, sq_val, k, weights_given, mask, sparse_host));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_search_sparse_batch(vr_engine* e, const int64_t* q_off, const int32_t* q_idx, const float* q_val, int32_t nq,
+                           int32_t k, int32_t weights_given, const vr_filter* filter, int64_t* rows, float* scores,
+                           int32_t* counts) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q_off && rows && scores && nq >= 1, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  VR_CHECK(q_off[nq] == q_off[0] || (q_idx && q_val), "null sparse queries");
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(false));
+  vr_engine* L = lane.L;
+  std::vector<uint64_t> keys(static_cast<size_t>(nq) * k, 0ull);
+  if (L->n_rows > 0 && L->n_slices_dev > 0) {
+    const uint8_t* mask = nullptr;
+    VR_TRY(filter_build_mask(L, filter, &mask));
+    VR_TRY(search_sparse_keys_locked(L, q_off, q_idx, q_val, nq, k, weights_given != 0, mask, keys.data()));
+  }
+  for (int i = 0; i < nq; ++i) {
+    const int64_t c = decode_keys(keys.data() + static_cast<size_t>(i) * k, k, rows + static_cast<int64_t>(i) * k,
+                                  scores + static_cast<int64_t>(i) * k);
+    if (counts) counts[i] = static_cast<int32_t>(c);
+  }
+  return 0;
+}
+
+int vr_search_hybrid_keys(vr_engine* e, const float* q, int32_t nq, int mem, const int64_t* sq_off, const int32_t* sq_idx,
+                          const float* sq_val, int32_t k, int32_t weights_given, const vr_filter* filter, uint64_t* keys,
+                          int keys_mem) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && keys && nq >= 1, "bad arguments");
+  VR_CHECK(k >= 1 && k <= kMaxK, "k = %d not in 1..%d", k, kMaxK);
+  VR_CHECK((mem == VR_MEM_HOST || mem == VR_MEM_DEVICE) && (keys_mem == VR_MEM_HOST || keys_mem == VR_MEM_DEVICE), "bad mem");
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(true));
+  vr_engine* L = lane.L;
+  const size_t per = static_cast<size_t>(nq) * k;
+  std::vector<uint64_t> dense(per), sparse(per);
+  VR_TRY(hybrid_keys_locked(L, q, nq, mem, sq_off, sq_idx, sq_val, k, weights_given != 0, filter, dense.data(), sparse.data()));
+  // [query][dense list, sparse list][k]
+  std::vector<uint64_t> both;
+  uint64_t* dst = keys;
+  if (keys_mem == VR_MEM_DEVICE) {
+    both.resize(2 * per);
+    dst = both.data();
+  }
+  for (int i = 0; i < nq; ++i) {
+    memcpy(dst + (2 * static_cast<size_t>(i)) * k, dense.data() + static_cast<size_t>(i) * k, sizeof(uint64_t) * k);
+    memcpy(dst + (2 * static_cast<size_t>(i) + 1) * k, sparse.data() + static_cast<size_t>(i) * k, sizeof(uint64_t) * k);
+  }
+  if (keys_mem == VR_MEM_DEVICE) {
+    VR_HIP(hipMemcpyAsync(keys, both.data(), sizeof(uint64_t) * 2 * per, hipMemcpyHostToDevice, L->stream));
+    VR_HIP(hipStreamSynchronize(L->stream));
+  }
+  return 0;
+}
+
+int vr_fuse_batch(const int64_t* d_rows, const float* d_scores, const int32_t* d_counts, const int64_t* s_rows,
+                  const float* s_scores, const int32_t* s_counts, int32_t nq, int32_t k, int32_t limit, double sparse_weight,
+                  int32_t fusion, int32_t json_scores, int64_t* out_rows, double* out_scores, int32_t* out_from_dense,
+                  int32_t* out_counts) {
+  return fuse_batch(d_rows, d_scores, d_counts, s_rows, s_scores, s_counts, nq, k, limit, sparse_weight, fusion, json_scores,
+                    out_rows, out_scores, out_from_dense, out_counts);
+}
+
+int vr_search_hybrid_batch(vr_engine* e, const float* q, int32_t nq, int mem, const int64_t* sq_off, const int32_t* sq_idx,
+                           const float* sq_val, int32_t limit, double sparse_weight, int32_t fusion, const vr_filter* filter,
+                           int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_counts) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(q && out_rows && out_scores && out_counts && nq >= 1, "bad arguments");
+  VR_CHECK(limit >= 1 && limit * 3 <= kMaxK, "limit = %d not in 1..%d", limit, kMaxK / 3);
+  VR_CHECK(fusion == VR_FUSION_MINMAX || fusion == VR_FUSION_RRF, "unknown fusion %d", fusion);
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  const int k = 3 * limit;  // prefetch_limit, vector_store.py:636
+  const size_t per = static_cast<size_t>(nq) * k;
+  std::vector<uint64_t> dense(per), sparse(per);
+  {
+    SearchLane lane(e);
+    VR_TRY(lane.acquire(mem == VR_MEM_DEVICE));
+    VR_TRY(hybrid_keys_locked(lane.L, q, nq, mem, sq_off, sq_idx, sq_val, k, false, filter, dense.data(), sparse.data()));
+  }
+  // fusion of every query on the host threads (vector_store.py:659-697, once per query)
+  std::atomic<int> failed{0};
+  parallel_for(nq, 8, [&](int64_t i) {
+    int64_t d_rows[kMaxK], s_rows[kMaxK];
+    float d_scores[kMaxK], s_scores[kMaxK];
+    const int nd = static_cast<int>(decode_keys(dense.data() + static_cast<size_t>(i) * k, k, d_rows, d_scores));
+    const int ns = static_cast<int>(decode_keys(sparse.data() + static_cast<size_t>(i) * k, k, s_rows, s_scores));
+    int32_t* fd = out_from_dense ? out_from_dense + i * limit : nullptr;
+    const int rc = fusion == VR_FUSION_MINMAX
+                       ? fuse_minmax(d_rows, d_scores, nd, s_rows, s_scores, ns, limit, sparse_weight, 1, out_rows + i * limit,
+                                     out_scores + i * limit, fd, out_counts + i)
+                       : fuse_rrf(d_rows, nd, s_rows, ns, limit, sparse_weight, out_rows + i * limit, out_scores + i * limit,
+                                  fd, out_counts + i);
+    if (rc != 0) failed.store(1);
+  });
+  VR_CHECK(!failed.load(), "fusion failed");
+  return 0;
+}
+
+int vr_merge_keys(vr_engine* e, const uint64_t* parts, int32_t n_parts, int32_t n_lists, int32_t k, int mem, int64_t* out_ids,
+                  float* out_scores, int32_t* out_counts) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(parts && out_ids && out_scores && n_parts >= 1 && n_lists >= 1 && k >= 1, "bad arguments");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  SearchLane lane(e);
+  VR_TRY(lane.acquire(mem == VR_MEM_DEVICE));
+  vr_engine* L = lane.L;
+  const int64_t total = static_cast<int64_t>(n_parts) * n_lists * k;
+  const uint64_t* parts_dev = parts;
+  if (mem == VR_MEM_HOST) {
+    VR_TRY(L->mg_in.grow(total, 0, L->stream));
+    VR_HIP(hipMemcpyAsync(L->mg_in.p, parts, sizeof(uint64_t) * static_cast<size_t>(total), hipMemcpyHostToDevice, L->stream));
+    parts_dev = L->mg_in.p;
+  }
+  const int64_t per = static_cast<int64_t>(n_lists) * k;
+  VR_TRY(L->mg_gid.grow(per, 0, L->stream));
+  VR_TRY(L->mg_score.grow(per, 0, L->stream));
+  VR_TRY(L->mg_cnt.grow(n_lists, 0, L->stream));
+  VR_TRY(topk_merge_parts(L, parts_dev, n_parts, n_lists, k, L->mg_gid.p, L->mg_score.p, L->mg_cnt.p));
+  VR_HIP(hipMemcpyAsync(out_ids, L->mg_gid.p, sizeof(int64_t) * static_cast<size_t>(per), hipMemcpyDeviceToHost, L->stream));
+  VR_HIP(hipMemcpyAsync(out_scores, L->mg_score.p, sizeof(float) * static_cast<size_t>(per), hipMemcpyDeviceToHost, L->stream));
+  std::vector<int32_t> cnt(static_cast<size_t>(n_lists));
+  VR_HIP(hipMemcpyAsync(cnt.data(), L->mg_cnt.p, sizeof(int32_t) * static_cast<size_t>(n_lists), hipMemcpyDeviceToHost, L->stream));
+  VR_HIP(hipStreamSynchronize(L->stream));
+  if (out_counts) memcpy(out_counts, cnt.data(), sizeof(int32_t) * static_cast<size_t>(n_lists));
+  return 0;
+}
+
+int vr_sparse_row_ids(vr_engine* e, const int64_t* rows, int64_t n, int32_t* out, int64_t cap, int mem, int32_t* stride,
+                      int64_t* n_points) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(stride != nullptr && n >= 0, "bad arguments");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> writer(e->wmu);  // (the master's staging arrays)
+  std::shared_lock<std::shared_mutex> view(e->rw);
+  const int w = sparse_max_width(e);
+  *stride = w;
+  if (n_points) *n_points = 0;
+  if (!out || n == 0 || w == 0) return 0;
+  VR_CHECK(rows != nullptr, "null rows");
+  const int64_t total = n * w;
+  VR_CHECK(cap >= total, "room for %lld ids, %lld needed", static_cast<long long>(cap), static_cast<long long>(total));
+  VR_TRY(e->stage_i64a.grow(n, 0, e->stream));
+  VR_HIP(hipMemcpyAsync(e->stage_i64a.p, rows, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, e->stream));
+  int32_t* out_dev = out;
+  if (mem == VR_MEM_HOST) {
+    VR_TRY(e->stage_i32a.grow(total, 0, e->stream));
+    out_dev = e->stage_i32a.p;
+  }
+  int64_t pts = 0;
+  VR_TRY(sparse_row_ids(e, e->stage_i64a.p, n, w, out_dev, &pts));
+  if (n_points) *n_points = pts;
+  if (mem == VR_MEM_HOST) {
+    VR_HIP(hipMemcpyAsync(out, out_dev, sizeof(int32_t) * static_cast<size_t>(total), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+int vr_df_apply(vr_engine* e, const int32_t* ids, int64_t n_ids, int mem, int64_t n_points, int32_t sign) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(n_ids >= 0 && (n_ids == 0 || ids) && (sign == 1 || sign == -1) && n_points >= 0, "bad arguments");
+  VR_CHECK(mem == VR_MEM_HOST || mem == VR_MEM_DEVICE, "bad mem %d", mem);
+  std::lock_guard<std::mutex> writer(e->wmu);
+  PublishLock publish(e);  // (the table may be re-hashed; searches read it)
+  const int32_t* ids_dev = ids;
+  if (mem == VR_MEM_HOST && n_ids > 0) {
+    VR_TRY(e->stage_i32a.grow(n_ids, 0, e->stream));
+    VR_HIP(hipMemcpyAsync(e->stage_i32a.p, ids, sizeof(int32_t) * static_cast<size_t>(n_ids), hipMemcpyHostToDevice, e->stream));
+    ids_dev = e->stage_i32a.p;
+  }
+  VR_TRY(sparse_df_apply(e, ids_dev, n_ids, sign));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  e->n_sparse_points += sign * n_points;
+  return 0;
 }
 
 }  // extern "C"

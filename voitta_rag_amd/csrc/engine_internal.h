@@ -269,6 +269,16 @@ struct vr_engine {
   vr::DevArray<uint16_t> bq_tile_ub;  // f16 bits: per (16-row tile, query) the largest upper bound (rounded up)
   vr::DevArray<int32_t> bq_pairs;     // per query: the tiles whose bound reaches its threshold ([nq][kBatchCand]), then the counts [nq]
   vr::DevArray<float> bq_stage;  // host queries staged on the device
+  // batched sparse search (invert.hip): the queries' terms as CSR (offsets, ascending distinct ids, raw values,
+  // weights q_t * idf_t) and the nq x k result keys
+  vr::DevArray<int32_t> sq_off, sq_ids;
+  vr::DevArray<float> sq_val, sq_w;
+  vr::DevArray<uint64_t> sq_keys;
+  // vr_merge_keys: the parts' keys staged on the device, merged global ids / scores / counts
+  vr::DevArray<uint64_t> mg_in;
+  vr::DevArray<int64_t> mg_gid;
+  vr::DevArray<float> mg_score;
+  vr::DevArray<int32_t> mg_cnt;
   // Pinned, device-mapped host scratch (1 MiB). Query inputs are written here by the host and
   // read by the kernels straight over PCIe, results are written here by the last kernel of a
   // search: the latency path of a query has no hipMemcpy at all.
@@ -368,8 +378,23 @@ void inv_release(vr_engine* e);
 bool inv_usable(const vr_engine* e, int nnz);
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
                   float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev);
+// many queries in one launch: CSR in device memory (ascending distinct ids, <= kInvMaxTerms per query; raw values in
+// q_val_dev, weights written to q_w_dev); nq x k keys to out_keys_dev
+int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q_ids_dev, const float* q_val_dev,
+                        float* q_w_dev, int nq, int n_terms, bool weights_given, float n_points, const uint8_t* mask_dev,
+                        int k, uint64_t* out_keys_dev);
 int sparse_scores(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz,
                   const uint8_t* mask_dev, bool weights_given);
+// term ids of the listed rows' sparse vectors as out_dev[i * stride + j] (-1: no such entry, dead row, no sparse
+// vector); *n_points_host = listed rows that are live and carry a sparse vector
+int sparse_max_width(const vr_engine* e);  // widest stored sparse row (a multiple of 4)
+int sparse_row_ids(vr_engine* e, const int64_t* rows_dev, int64_t n, int stride, int32_t* out_dev, int64_t* n_points_host);
+// df[id] += sign for every id >= 0 of ids_dev (document frequencies of rows stored on OTHER shards)
+int sparse_df_apply(vr_engine* e, const int32_t* ids_dev, int64_t n, int sign);
+// topk.hip: merge n_parts result lists per (query, list) — parts_dev [n_parts][n_lists][k] keys — into global ids
+// (row * n_parts + part), scores and counts, device arrays [n_lists][k] / [n_lists]
+int topk_merge_parts(vr_engine* e, const uint64_t* parts_dev, int n_parts, int n_lists, int k, int64_t* gid_dev,
+                     float* score_dev, int32_t* cnt_dev);
 int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t* n_deleted,
                        int64_t* n_sparse_deleted);
 int sparse_lookup_df(vr_engine* e, const int32_t* ids_host, int n, int32_t* out_df_host);
@@ -398,6 +423,10 @@ int fuse_minmax(const int64_t* d_rows, const float* d_scores, int nd, const int6
 int fuse_rrf(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, int limit,
              double sparse_weight, int64_t* out_rows, double* out_scores, int32_t* out_from_dense,
              int32_t* out_count);
+
+int fuse_batch(const int64_t* d_rows, const float* d_scores, const int32_t* d_counts, const int64_t* s_rows,
+               const float* s_scores, const int32_t* s_counts, int nq, int k, int limit, double sparse_weight, int fusion,
+               int json_scores, int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_counts);
 
 inline uint32_t f32_order_bits(float f) {
   uint32_t u;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "host_parallel.h"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -144,6 +145,32 @@ int fuse_rrf(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, int l
     c.in_sparse = true;
   }
   return emit(all, limit, out_rows, out_scores, out_from_dense, out_count);
+}
+
+// nq pairs of lists at once, one query per host thread at a time (the last step of a batched or sharded hybrid
+// search: vector_store.py:659-697 per query). d_* / s_*: [nq][k] with counts; out_*: [nq][limit].
+int fuse_batch(const int64_t* d_rows, const float* d_scores, const int32_t* d_counts, const int64_t* s_rows,
+               const float* s_scores, const int32_t* s_counts, int nq, int k, int limit, double sparse_weight, int fusion,
+               int json_scores, int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_counts) {
+  VR_CHECK(nq >= 0 && k >= 1 && limit >= 1 && d_rows && d_scores && d_counts && out_rows && out_scores && out_counts,
+           "bad arguments");
+  VR_CHECK(fusion == VR_FUSION_MINMAX || fusion == VR_FUSION_RRF, "unknown fusion %d", fusion);
+  std::atomic<int> failed{0};
+  parallel_for(nq, 8, [&](int64_t i) {
+    const int nd = std::max(0, std::min<int>(d_counts[i], k));
+    const int ns = (s_counts && s_rows && s_scores) ? std::max(0, std::min<int>(s_counts[i], k)) : 0;
+    const int64_t* sr = s_rows ? s_rows + i * k : nullptr;
+    const float* ss = s_scores ? s_scores + i * k : nullptr;
+    int32_t* fd = out_from_dense ? out_from_dense + i * limit : nullptr;
+    const int rc = fusion == VR_FUSION_MINMAX
+                       ? fuse_minmax(d_rows + i * k, d_scores + i * k, nd, sr, ss, ns, limit, sparse_weight, json_scores,
+                                     out_rows + i * limit, out_scores + i * limit, fd, out_counts + i)
+                       : fuse_rrf(d_rows + i * k, nd, sr, ns, limit, sparse_weight, out_rows + i * limit,
+                                  out_scores + i * limit, fd, out_counts + i);
+    if (rc != 0) failed.store(1);
+  });
+  VR_CHECK(!failed.load(), "fusion failed");
+  return 0;
 }
 
 }  // namespace vr

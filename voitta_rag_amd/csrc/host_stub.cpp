@@ -39,4 +39,12 @@ int vr_fuse_rrf(const int64_t* d_rows, int32_t nd, const int64_t* s_rows, int32_
   return vr::fuse_rrf(d_rows, nd, s_rows, ns, limit, 0.0, out_rows, out_scores, out_from_dense, out_count);
 }
 
+int vr_fuse_batch(const int64_t* d_rows, const float* d_scores, const int32_t* d_counts, const int64_t* s_rows,
+                  const float* s_scores, const int32_t* s_counts, int32_t nq, int32_t k, int32_t limit, double sparse_weight,
+                  int32_t fusion, int32_t json_scores, int64_t* out_rows, double* out_scores, int32_t* out_from_dense,
+                  int32_t* out_counts) {
+  return vr::fuse_batch(d_rows, d_scores, d_counts, s_rows, s_scores, s_counts, nq, k, limit, sparse_weight, fusion,
+                        json_scores, out_rows, out_scores, out_from_dense, out_counts);
+}
+
 }  // extern "C"

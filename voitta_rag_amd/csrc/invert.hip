@@ -409,31 +409,33 @@ struct InvQuery {
   float val[kInvMaxTerms];
 };
 
-__global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
-    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
-    const InvQuery query, int nnz, int weights_given,
-    const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
-    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
-  __shared__ float score[kInvSegRows];
-  __shared__ uint8_t hit[kInvSegRows];
-  __shared__ int32_t t_id[kInvMaxTerms];
-  __shared__ float t_w[kInvMaxTerms];
-  __shared__ int32_t t_lo[kInvMaxTerms];
-  __shared__ uint64_t lists[kInvWaves * kListLen];
-  __shared__ uint64_t tmax[kInvWaves * 64];
-  __shared__ uint64_t blk_thr;
+// LDS of one block of the inverted scan (single-query and batched kernels share it and the body below)
+struct InvShared {
+  float score[kInvSegRows];
+  uint8_t hit[kInvSegRows];
+  int32_t t_id[kInvMaxTerms];
+  float t_w[kInvMaxTerms];
+  int32_t t_lo[kInvMaxTerms];
+  uint64_t lists[kInvWaves * kListLen];
+  uint64_t tmax[kInvWaves * 64];
+  uint64_t blk_thr;
+};
+
+// The block's share of the segments (s0, s0 + s_step, ...) for ONE query whose terms (ascending ids) and weights
+// already sit in sh.t_id / sh.t_w; leaves the block's k best keys in sh.lists[0 .. kListLen) (wave 0's list).
+__device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* __restrict__ segs, int n_seg, int s0,
+                                                  int s_step, const uint64_t* __restrict__ keys,
+                                                  const float* __restrict__ vals, int nnz,
+                                                  const uint8_t* __restrict__ mask, int k) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  uint64_t* list = lists + wave * kListLen;
-  lists[threadIdx.x] = 0ull;  // blockDim.x == kInvWaves * kListLen
-  if (static_cast<int>(threadIdx.x) < nnz) {
-    const int32_t id = query.id[threadIdx.x];
-    t_id[threadIdx.x] = id;
-    t_w[threadIdx.x] = sparse_query_weight(query.val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
-  }
-  __syncthreads();
-
-  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+  uint64_t* list = sh.lists + wave * kListLen;
+  float* score = sh.score;
+  uint8_t* hit = sh.hit;
+  const int32_t* t_id = sh.t_id;
+  const float* t_w = sh.t_w;
+  int32_t* t_lo = sh.t_lo;
+  for (int s = s0; s < n_seg; s += s_step) {
     const InvSeg seg = segs[s];
     if (seg.count == 0) continue;  // block-uniform
     const uint64_t* kp = keys + seg.off;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
         }
       }
     }
-    if (threadIdx.x == 0) blk_thr = 0ull;
+    if (threadIdx.x == 0) sh.blk_thr = 0ull;
     __syncthreads();
     // Selection. Thousands of rows may have been hit and a list insert is serial work for its wave, so first a
     // bound: a thread takes rows tid, tid + 256, ...; the k-th largest of the 256 per-thread maxima has k keys at or
@@ -520,15 +522,15 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
       rkey[j] = (in && mask[row]) ? topk_make_key(score[r], row) : 0ull;
       best = rkey[j] > best ? rkey[j] : best;
     }
-    tmax[threadIdx.x] = best;
+    sh.tmax[threadIdx.x] = best;
     __syncthreads();
     if (best) {
       int rank = 0;
-      for (int j = 0; j < kInvWaves * 64; ++j) rank += tmax[j] > best;
-      if (rank == k - 1) blk_thr = best;
+      for (int j = 0; j < kInvWaves * 64; ++j) rank += sh.tmax[j] > best;
+      if (rank == k - 1) sh.blk_thr = best;
     }
     __syncthreads();
-    const uint64_t thr = blk_thr;
+    const uint64_t thr = sh.blk_thr;
 #pragma unroll
     for (int j = 0; j < kInvSegRows / (kInvWaves * 64); ++j) {
       if (j * kInvWaves * 64 >= seg.nrows) break;  // block-uniform
@@ -537,8 +539,58 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     }
     __syncthreads();  // the next segment clears the accumulators
   }
-  block_merge_lists(lists, kListLen, kInvWaves, wave, lane);
-  if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = list[lane];
+  block_merge_lists(sh.lists, kListLen, kInvWaves, wave, lane);
+}
+
+__global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
+    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
+    const InvQuery query, int nnz, int weights_given,
+    const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
+  __shared__ InvShared sh;
+  sh.lists[threadIdx.x] = 0ull;  // blockDim.x == kInvWaves * kListLen
+  if (static_cast<int>(threadIdx.x) < nnz) {
+    const int32_t id = query.id[threadIdx.x];
+    sh.t_id[threadIdx.x] = id;
+    sh.t_w[threadIdx.x] = sparse_query_weight(query.val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
+  }
+  __syncthreads();
+  inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k);
+  if (threadIdx.x < kListLen) cand[static_cast<int64_t>(blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
+}
+
+// ---- many queries per launch (vr_search_sparse_batch, the sparse leg of vr_search_hybrid_batch; BASELINE
+// configs[4]: 1k batched hybrid queries). The reference call this stands for is the sparse query_points of
+// vector_store.py:647-656, once per query. Same body, same bits: grid (segment share, query).
+
+// q_t * idf_t for every term of every query of the batch, once (instead of once per block)
+__global__ void sparse_batch_weights_kernel(const int32_t* __restrict__ ids, const float* __restrict__ vals, int n,
+                                            int weights_given, const int32_t* __restrict__ df_keys,
+                                            const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
+                                            float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sparse_query_weight(vals[i], ids[i], weights_given, df_keys, df_cnt, df_cap, n_points);
+}
+
+// q_off[nq + 1]: the terms of query y are ids / w [q_off[y], q_off[y + 1]) — ascending, distinct, at most
+// kInvMaxTerms (a query with none, or one the host serves another way, has an empty range and gets empty lists)
+__global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
+    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
+    const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
+  __shared__ InvShared sh;
+  const int qy = blockIdx.y;
+  const int t0 = q_off[qy];
+  const int nnz = min(q_off[qy + 1] - t0, kInvMaxTerms);
+  sh.lists[threadIdx.x] = 0ull;
+  if (static_cast<int>(threadIdx.x) < nnz) {
+    sh.t_id[threadIdx.x] = q_ids[t0 + threadIdx.x];
+    sh.t_w[threadIdx.x] = q_w[t0 + threadIdx.x];
+  }
+  __syncthreads();
+  if (nnz > 0) inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k);  // block-uniform
+  if (threadIdx.x < kListLen)
+    cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
 
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
@@ -561,6 +613,30 @@ int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
   prof_end(e);
   VR_HIP(hipGetLastError());
   return topk_merge_lists(e, e->sp_cand.p, blocks, 1, k, out_keys_dev);
+}
+
+// nq queries in device memory (CSR as sparse_inv_batch_kernel takes it, raw values in q_val_dev) -> nq x k keys in
+// out_keys_dev (device-visible). Queries with an empty term range come out as empty lists.
+int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q_ids_dev, const float* q_val_dev,
+                        float* q_w_dev, int nq, int n_terms, bool weights_given, float n_points, const uint8_t* mask_dev,
+                        int k, uint64_t* out_keys_dev) {
+  VR_CHECK(nq >= 1 && k >= 1 && k <= kListLen, "bad inverted-scan shape");
+  if (n_terms > 0)
+    hipLaunchKernelGGL(sparse_batch_weights_kernel, dim3(static_cast<unsigned>((n_terms + 255) / 256)), dim3(256), 0,
+                       e->stream, q_ids_dev, q_val_dev, n_terms, weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap,
+                       n_points, q_w_dev);
+  // a block walks its share of the segments for one query; enough blocks to fill the chip several times over, few
+  // enough lists per query for one merge block (and a candidate array of nq x gx x 512 B)
+  int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (16384 + nq - 1) / nq)));
+  gx = std::min(gx, kScanBlocks);
+  VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * gx * kListLen, 0, e->stream));
+  prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
+  hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
+                     0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
+                     q_ids_dev, q_w_dev, mask_dev, k, e->sp_cand.p);
+  prof_end(e);
+  VR_HIP(hipGetLastError());
+  return topk_merge_lists(e, e->sp_cand.p, gx, nq, k, out_keys_dev);
 }
 
 }  // namespace vr

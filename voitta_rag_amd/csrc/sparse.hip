@@ -143,7 +143,7 @@ constexpr int kDfSlots = 8192;  // LDS hash slots (load factor <= 0.5)
 
 __global__ __launch_bounds__(256) void df_update_region_kernel(const int32_t* __restrict__ sidx, int64_t begin,
                                                                int64_t end, int32_t* keys, int32_t* cnt,
-                                                               int64_t cap, int32_t* distinct) {
+                                                               int64_t cap, int32_t* distinct, int sign) {
   __shared__ int32_t lk[kDfSlots];
   __shared__ int32_t lc[kDfSlots];
   for (int i = threadIdx.x; i < kDfSlots; i += 256) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void df_update_region_kernel(const int32_t* __
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kDfSlots; i += 256)
-    if (lk[i] != -1) df_add(keys, cnt, cap, lk[i], lc[i], distinct);
+    if (lk[i] != -1) df_add(keys, cnt, cap, lk[i], sign * lc[i], distinct);
 }
 
 int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt_host,
@@ -213,7 +213,7 @@ int sparse_append(vr_engine* e, int64_t n, int64_t first_row, const int32_t* cnt
   if (region > 0 && account)
     hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((region + kDfChunk - 1) / kDfChunk)),
                        dim3(256), 0, e->stream, e->sp_idx.p, e->sp_used, used, e->df_keys.p,
-                       e->df_cnt.p, e->df_cap, e->df_distinct);
+                       e->df_cnt.p, e->df_cap, e->df_distinct, 1);
   VR_HIP(hipGetLastError());
   e->sp_used = used;
   e->n_slices_dev = static_cast<int64_t>(e->slices_host.size());
@@ -420,6 +420,67 @@ int sparse_delete_rows(vr_engine* e, const int64_t* rows_dev, int64_t n, int64_t
   VR_HIP(hipStreamSynchronize(e->stream));
   *n_deleted = c[0];
   *n_sparse_deleted = c[1];
+  return 0;
+}
+
+// ---- document frequencies across shards (sharded.py; SURVEY.md §8e: the df deltas of every upsert / delete batch
+// are summed over the shards at index time, so that a query finds the collection-wide statistic — Qdrant's
+// Modifier.IDF scope, vector_store.py:95-99 — in its own engine's table and needs no exchange of its own) ----------
+
+// one thread per (row, entry slot): the term ids of the listed rows in a fixed-stride layout, -1 where the row has no
+// such entry, is dead, or carries no sparse vector; counter += live rows with a sparse vector
+__global__ void sparse_row_ids_kernel(const int64_t* __restrict__ rows, int64_t n, int stride, int64_t n_rows,
+                                      const uint8_t* __restrict__ live, const int32_t* __restrict__ row_slice,
+                                      const SliceDesc* __restrict__ slices, const int32_t* __restrict__ sidx,
+                                      int32_t* __restrict__ out, unsigned long long* counter) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * stride) return;
+  const int64_t i = t / stride;
+  const int j = static_cast<int>(t - i * stride);
+  const int64_t row = rows[i];
+  int32_t id = -1;
+  if (row >= 0 && row < n_rows && live[row]) {
+    const int32_t s = row_slice[row];
+    if (s >= 0) {
+      const SliceDesc d = slices[s];
+      const int lane = static_cast<int>(row - d.row_base);
+      if (j < d.width) id = sidx[d.off + static_cast<int64_t>(j >> 2) * 256 + lane * 4 + (j & 3)];
+      if (j == 0) atomicAdd(counter, 1ull);
+    }
+  }
+  out[t] = id;
+}
+
+int sparse_max_width(const vr_engine* e) {
+  int w = 0;
+  for (const SliceDesc& d : e->slices_host) w = std::max(w, d.width);
+  return w;
+}
+
+int sparse_row_ids(vr_engine* e, const int64_t* rows_dev, int64_t n, int stride, int32_t* out_dev, int64_t* n_points_host) {
+  *n_points_host = 0;
+  if (n <= 0 || stride <= 0) return 0;
+  VR_TRY(e->stage_i64b.grow(1, 0, e->stream));
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(e->stage_i64b.p);
+  VR_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), e->stream));
+  const int64_t total = n * stride;
+  hipLaunchKernelGGL(sparse_row_ids_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, e->stream,
+                     rows_dev, n, stride, e->n_rows, e->live.p, e->row_slice.p, e->slices.p, e->sp_idx.p, out_dev, counter);
+  VR_HIP(hipGetLastError());
+  unsigned long long c = 0;
+  VR_HIP(hipMemcpyAsync(&c, counter, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  *n_points_host = static_cast<int64_t>(c);
+  return 0;
+}
+
+int sparse_df_apply(vr_engine* e, const int32_t* ids_dev, int64_t n, int sign) {
+  if (n <= 0) return 0;
+  VR_TRY(df_ensure(e, sign > 0 ? n : 0));
+  hipLaunchKernelGGL(df_update_region_kernel, dim3(static_cast<unsigned>((n + kDfChunk - 1) / kDfChunk)), dim3(256), 0,
+                     e->stream, ids_dev, static_cast<int64_t>(0), n, e->df_keys.p, e->df_cnt.p, e->df_cap, e->df_distinct,
+                     sign > 0 ? 1 : -1);
+  VR_HIP(hipGetLastError());
   return 0;
 }
 

@@ -224,6 +224,64 @@ int topk_merge_lists(vr_engine* e, uint64_t* cand, int n_lists, int nq, int k, u
   return 0;
 }
 
+// ---- merging the result lists of several shards (vr_merge_keys; sharded.py after its all_gather) ---------------
+//
+// parts[p][l][0..k): shard p's keys of list l (descending, 0 = empty), rows local to the shard. One block per list:
+// every key is ranked against all others — larger key first, equal keys (same score bits, same local row) by the
+// lower shard — which is the single-engine order of the global ids row * n_parts + p whenever rows were dealt
+// round-robin. <= 4096 keys per list; integer compares out of LDS.
+constexpr int kPartsMax = 4096;
+
+__global__ __launch_bounds__(256) void merge_parts_kernel(const uint64_t* __restrict__ parts, int n_parts, int n_lists,
+                                                          int k, int64_t* __restrict__ gid, float* __restrict__ score,
+                                                          int32_t* __restrict__ cnt) {
+  __shared__ uint64_t keys[kPartsMax];
+  __shared__ int total;
+  const int l = blockIdx.x;
+  const int n = n_parts * k;
+  if (threadIdx.x == 0) total = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int p = i / k, j = i - p * k;
+    keys[i] = parts[(static_cast<int64_t>(p) * n_lists + l) * k + j];
+  }
+  for (int j = threadIdx.x; j < k; j += 256) {
+    gid[static_cast<int64_t>(l) * k + j] = -1;
+    score[static_cast<int64_t>(l) * k + j] = 0.0f;
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint64_t key = keys[i];
+    if (key == 0) continue;
+    ++mine;
+    int rank = 0;
+    for (int o = 0; o < n; ++o) {
+      const uint64_t ok = keys[o];
+      rank += (ok > key) || (ok == key && o < i);  // o < i among equal keys == lower shard (a shard's keys are distinct)
+    }
+    if (rank < k) {
+      const uint32_t hi = static_cast<uint32_t>(key >> 32);
+      const uint32_t u = (hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi;
+      const int64_t row = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(key & 0xFFFFFFFFu));
+      gid[static_cast<int64_t>(l) * k + rank] = row * n_parts + i / k;
+      score[static_cast<int64_t>(l) * k + rank] = __uint_as_float(u);
+    }
+  }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[l] = total < k ? total : k;
+}
+
+int topk_merge_parts(vr_engine* e, const uint64_t* parts_dev, int n_parts, int n_lists, int k, int64_t* gid_dev,
+                     float* score_dev, int32_t* cnt_dev) {
+  VR_CHECK(n_parts >= 1 && n_lists >= 1 && k >= 1 && n_parts * k <= kPartsMax, "merge of %d parts x %d keys (at most %d keys per list)",
+           n_parts, k, kPartsMax);
+  hipLaunchKernelGGL(merge_parts_kernel, dim3(static_cast<unsigned>(n_lists)), dim3(256), 0, e->stream, parts_dev, n_parts,
+                     n_lists, k, gid_dev, score_dev, cnt_dev);
+  VR_HIP(hipGetLastError());
+  return 0;
+}
+
 int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, int nq, int k,
                 const uint64_t** out_keys) {
   VR_CHECK(k >= 1 && k <= kMaxK, "top-k of %d not in 1..%d", k, kMaxK);

@@ -421,6 +421,148 @@ class Engine:
         n = int(cnt[0])
         return rows[:n].copy(), scores[:n].copy(), fd[:n].copy()
 
+    # ---- many queries per call (BASELINE configs[4]: 1k batched hybrid queries) -----------------------------------
+    @staticmethod
+    def _sparse_csr(sparse_queries, nq: int):
+        """[(indices, values)] per query (None / empty = no sparse terms) -> CSR (off int64, idx int32, val f32)."""
+        assert len(sparse_queries) == nq
+        off = np.zeros(nq + 1, np.int64)
+        idx, val = [], []
+        for i, sq in enumerate(sparse_queries):
+            n = 0
+            if sq is not None and len(sq[0]) > 0:
+                qi, qv = _np(sq[0], np.int32).reshape(-1), _np(sq[1], np.float32).reshape(-1)
+                assert qi.shape == qv.shape
+                idx.append(qi)
+                val.append(qv)
+                n = qi.shape[0]
+            off[i + 1] = off[i] + n
+        idx = np.concatenate(idx) if idx else np.zeros(0, np.int32)
+        val = np.concatenate(val) if val else np.zeros(0, np.float32)
+        return off, _np(idx, np.int32), _np(val, np.float32)
+
+    def _queries(self, queries):
+        if _is_device_tensor(queries):
+            self._follow(queries)
+            assert queries.is_contiguous() and int(queries.shape[-1]) == self.dim
+            return VR_MEM_DEVICE, int(queries.shape[0]), C.c_void_p(queries.data_ptr()), queries
+        q = _np(queries, np.float32).reshape(-1, self.dim)
+        return VR_MEM_HOST, q.shape[0], C.c_void_p(q.ctypes.data), q
+
+    def search_sparse_batch(self, sparse_queries, k: int, flt: SearchFilter | None = None, weights_given: bool = False):
+        """nq sparse searches in one call -> list of (rows int64[c], scores f32[c]); bit for bit nq x search_sparse."""
+        nq = len(sparse_queries)
+        if nq == 0:
+            return []
+        off, idx, val = self._sparse_csr(sparse_queries, nq)
+        rows = np.empty((nq, k), np.int64)
+        scores = np.empty((nq, k), np.float32)
+        counts = np.zeros(nq, np.int32)
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_search_sparse_batch(self._h, _ptr(off, C.c_int64), _ptr(idx, C.c_int32), _ptr(val, C.c_float), nq, k,
+                                               int(weights_given), fp, _ptr(rows, C.c_int64), _ptr(scores, C.c_float),
+                                               _ptr(counts, C.c_int32)))
+        del keep
+        return [(rows[i, : counts[i]].copy(), scores[i, : counts[i]].copy()) for i in range(nq)]
+
+    def search_hybrid_batch(self, queries, sparse_queries, limit: int, sparse_weight: float = 0.1,
+                            fusion: int = VR_FUSION_MINMAX, flt: SearchFilter | None = None, raw: bool = False):
+        """nq hybrid searches in ONE call (one batched dense search, one batched sparse search beside it, fusion on
+        the host threads) -> list of (rows int64[c], fused scores f64[c], from_dense int32[c]) per query, bit for bit
+        what nq x search_hybrid return. raw=True: the (nq, limit) arrays and the counts instead of the list."""
+        mem, nq, qp, keepq = self._queries(queries)
+        off, idx, val = self._sparse_csr(sparse_queries, nq)
+        rows = np.empty((nq, limit), np.int64)
+        scores = np.empty((nq, limit), np.float64)
+        fd = np.empty((nq, limit), np.int32)
+        counts = np.zeros(nq, np.int32)
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_search_hybrid_batch(self._h, qp, nq, mem, _ptr(off, C.c_int64), _ptr(idx, C.c_int32),
+                                               _ptr(val, C.c_float), limit, float(sparse_weight), fusion, fp,
+                                               _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32),
+                                               _ptr(counts, C.c_int32)))
+        del keep, keepq
+        if raw:
+            return rows, scores, fd, counts
+        return [(rows[i, : counts[i]].copy(), scores[i, : counts[i]].copy(), fd[i, : counts[i]].copy()) for i in range(nq)]
+
+    def search_hybrid_keys(self, queries, sparse_queries, k: int, flt: SearchFilter | None = None,
+                           weights_given: bool = False, out=None):
+        """Both legs of nq hybrid queries as packed ranking keys, (nq, 2, k) uint64: per query its dense list, then
+        its sparse list. ``out``: an (nq, 2, k) int64 device tensor to write them into (the tensor a sharded caller
+        hands to its all_gather), else a NumPy array is returned."""
+        mem, nq, qp, keepq = self._queries(queries)
+        off, idx, val = self._sparse_csr(sparse_queries, nq)
+        fp, keep = self._filter(flt)
+        args = (self._h, qp, nq, mem, _ptr(off, C.c_int64), _ptr(idx, C.c_int32), _ptr(val, C.c_float), k, int(weights_given), fp)
+        if out is not None:
+            assert _is_device_tensor(out) and out.is_contiguous() and tuple(out.shape) == (nq, 2, k) and out.element_size() == 8
+            self._follow(out)
+            check(self._lib.vr_search_hybrid_keys(*args, C.c_void_p(out.data_ptr()), VR_MEM_DEVICE))
+            return out
+        keys = np.empty((nq, 2, k), np.uint64)
+        check(self._lib.vr_search_hybrid_keys(*args, C.c_void_p(keys.ctypes.data), VR_MEM_HOST))
+        del keep, keepq
+        return keys
+
+    def merge_keys(self, parts, k: int):
+        """parts: (n_parts, n_lists, k) packed keys — a NumPy uint64 array or an int64 device tensor (what an all_gather
+        of search_dense_keys / search_hybrid_keys outputs filled). -> (global ids int64 (n_lists, k), -1 padded;
+        scores f32 (n_lists, k); counts int32 (n_lists,)), merged per list: score descending, then ascending global id
+        row * n_parts + part."""
+        if _is_device_tensor(parts):
+            self._follow(parts)
+            assert parts.is_contiguous() and parts.element_size() == 8
+            n_parts, n_lists = int(parts.shape[0]), int(np.prod(tuple(parts.shape)[1:-1]))
+            mem, pp, keep = VR_MEM_DEVICE, C.c_void_p(parts.data_ptr()), parts
+        else:
+            a = np.ascontiguousarray(parts).view(np.uint64)
+            n_parts, n_lists = a.shape[0], int(np.prod(a.shape[1:-1]))
+            mem, pp, keep = VR_MEM_HOST, C.c_void_p(a.ctypes.data), a
+        assert int(parts.shape[-1]) == k
+        ids = np.empty((n_lists, k), np.int64)
+        scores = np.empty((n_lists, k), np.float32)
+        counts = np.zeros(n_lists, np.int32)
+        check(self._lib.vr_merge_keys(self._h, pp, n_parts, n_lists, k, mem, _ptr(ids, C.c_int64), _ptr(scores, C.c_float),
+                                      _ptr(counts, C.c_int32)))
+        del keep
+        return ids, scores, counts
+
+    # ---- collection-wide document frequencies on a sharded corpus ----------------------------------------------------
+    def sparse_row_ids(self, rows, device: bool = False):
+        """Term ids of the listed rows' sparse vectors, (n, stride) int32 with -1 padding (dead rows and rows without
+        a sparse vector: all -1), and the number of listed rows that are live and carry one. device=True: a torch
+        tensor on the engine's device."""
+        r = _np(rows, np.int64)
+        stride, pts = C.c_int32(), C.c_int64()
+        check(self._lib.vr_sparse_row_ids(self._h, _ptr(r, C.c_int64), r.shape[0], None, 0, VR_MEM_HOST, C.byref(stride), C.byref(pts)))
+        w = int(stride.value)
+        if device:
+            import torch
+
+            out = torch.full((r.shape[0], w), -1, dtype=torch.int32, device=torch.device("cuda", self.device))
+            if out.numel():
+                self._follow(out)
+                check(self._lib.vr_sparse_row_ids(self._h, _ptr(r, C.c_int64), r.shape[0], C.c_void_p(out.data_ptr()), out.numel(),
+                                                  VR_MEM_DEVICE, C.byref(stride), C.byref(pts)))
+            return out, int(pts.value)
+        out = np.full((r.shape[0], w), -1, np.int32)
+        if out.size:
+            check(self._lib.vr_sparse_row_ids(self._h, _ptr(r, C.c_int64), r.shape[0], C.c_void_p(out.ctypes.data), out.size,
+                                              VR_MEM_HOST, C.byref(stride), C.byref(pts)))
+        return out, int(pts.value)
+
+    def df_apply(self, ids, n_points: int, sign: int = 1) -> None:
+        """Add (sign = +1) or remove (-1) the statistics of rows stored on OTHER shards: df[id] += sign per id >= 0,
+        sparse point count += sign * n_points."""
+        if _is_device_tensor(ids):
+            self._follow(ids)
+            assert ids.is_contiguous() and ids.element_size() == 4
+            check(self._lib.vr_df_apply(self._h, C.c_void_p(ids.data_ptr()), int(ids.numel()), VR_MEM_DEVICE, int(n_points), int(sign)))
+            return
+        a = _np(ids, np.int32).reshape(-1)
+        check(self._lib.vr_df_apply(self._h, C.c_void_p(a.ctypes.data), a.shape[0], VR_MEM_HOST, int(n_points), int(sign)))
+
 
 def fuse_minmax(d_rows, d_scores, s_rows, s_scores, limit: int, sparse_weight: float, json_scores: bool = True):
     """Host-only: the arithmetic of _hybrid_search on two result lists (no GPU needed)."""
@@ -450,3 +592,23 @@ def fuse_rrf(d_rows, s_rows, limit: int):
     check(lib.vr_fuse_rrf(_ptr(dr, C.c_int64), dr.shape[0], _ptr(sr, C.c_int64), sr.shape[0], limit,
                           _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32), C.byref(c)))
     return rows[: c.value].copy(), scores[: c.value].copy(), fd[: c.value].copy()
+
+
+def fuse_batch(d_ids, d_scores, d_counts, s_ids, s_scores, s_counts, limit: int, sparse_weight: float,
+               fusion: int = VR_FUSION_MINMAX, json_scores: bool = True):
+    """Host-only: fusion of nq pairs of lists ((nq, k) arrays + counts) on the host threads ->
+    (rows (nq, limit) int64, scores (nq, limit) f64, from_dense (nq, limit) int32, counts (nq,) int32)."""
+    lib = _lib.load_library()
+    dr, ds, dc = _np(d_ids, np.int64), _np(d_scores, np.float32), _np(d_counts, np.int32)
+    nq, k = dr.shape
+    sr, ss, sc = _np(s_ids, np.int64), _np(s_scores, np.float32), _np(s_counts, np.int32)
+    assert sr.shape == (nq, k) and ds.shape == (nq, k) and ss.shape == (nq, k)
+    rows = np.empty((nq, limit), np.int64)
+    scores = np.empty((nq, limit), np.float64)
+    fd = np.empty((nq, limit), np.int32)
+    counts = np.zeros(nq, np.int32)
+    check(lib.vr_fuse_batch(_ptr(dr, C.c_int64), _ptr(ds, C.c_float), _ptr(dc, C.c_int32), _ptr(sr, C.c_int64),
+                            _ptr(ss, C.c_float), _ptr(sc, C.c_int32), nq, k, limit, float(sparse_weight), fusion,
+                            int(json_scores), _ptr(rows, C.c_int64), _ptr(scores, C.c_double), _ptr(fd, C.c_int32),
+                            _ptr(counts, C.c_int32)))
+    return rows, scores, fd, counts
