@@ -70,7 +70,7 @@ def store(monkeypatch):
     from voitta_rag_amd import encoder as enc
 
     monkeypatch.setenv("EMBEDDING_DIMENSION", str(DIM))
-    monkeypatch.delenv("VOITTA_DEFERRED_INDEXING", raising=False)
+    monkeypatch.setenv("VOITTA_DEFERRED_INDEXING", "1")  # the opt-in write-behind; the default is checked by its own test below
     config.get_settings.cache_clear()
     engine = ToyEngine(DIM)
     store_registry.set_engine(engine)
@@ -201,6 +201,8 @@ def test_a_failed_fused_call_takes_its_rows_back_and_is_reported(store):
     with pytest.raises(RuntimeError, match="could not be completed"):
         vs.flush()
     assert vs.count_by_file("bad.md") == 0 and vs.count_by_file("ok.md") == 3 and engine.count() == (3, 3)
+    # the files whose rows were taken back are named, so that a caller with its own bookkeeping can map the failure
+    assert vs.failed_file_paths() == ["bad.md"] and vs.failed_file_paths() == []
     emb, sp, metas, _ = store.file_of("next.md", 2)  # the store keeps working, rows stay aligned
     vs.store_chunks([(f"n:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
     vs.flush()
@@ -238,3 +240,68 @@ def test_switch_off_and_concurrent_callers(store, monkeypatch):
             assert np.array_equal(engine.x[rows], ocore.cosine_preprocess(toy_embed(ids, off)))
     monkeypatch.setenv("VOITTA_DEFERRED_INDEXING", "0")
     assert not store.deferred.enabled()
+
+
+def test_default_mode_keeps_the_reference_failure_contract(store, monkeypatch):
+    """VOITTA_DEFERRED_INDEXING unset: the embeddings are still references (no Python floats), but store_chunks makes
+    its ONE fused call itself and raises if it fails — where the reference's upsert raises (vector_store.py:311-313),
+    so that IndexingService marks the file failed instead of committing it (indexing.py:558-590)."""
+    monkeypatch.delenv("VOITTA_DEFERRED_INDEXING", raising=False)
+    assert store.deferred.enabled() and not store.deferred.write_behind()
+    vs, engine = store.vs, store.engine
+    emb, sp, metas, r = store.file_of("a.md", 4)
+    vs.store_chunks([(f"a:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    assert engine.batches == [4] and engine.encodes == 0 and engine.count() == (4, 4)   # in the engine when the call returns
+    assert not emb.materialized and vs._col.flusher is None                              # no floats, no queue
+    assert np.array_equal(engine.x, ocore.cosine_preprocess(toy_embed(r[0], r[1])))
+    engine.fail_next = True
+    emb, sp, metas, _ = store.file_of("bad.md", 3)
+    with pytest.raises(RuntimeError, match="engine said no"):
+        vs.store_chunks([(f"bad:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    assert vs.count_by_file("bad.md") == 0 and engine.count() == (4, 4)
+    emb, sp, metas, _ = store.file_of("b.md", 2)
+    vs.store_chunks([(f"b:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    assert engine.count() == (6, 6) and vs.count_by_file("b.md") == 2
+
+
+def test_a_search_waits_for_the_stores_before_it_only(store):
+    """_drain works on sequence numbers: a search waits until the stores that returned BEFORE it are in the engine,
+    not until an indexing thread that keeps queueing has gone quiet; and a failed background store is not raised out
+    of an unrelated search."""
+    vs, engine = store.vs, store.engine
+    engine.delay = 0.02
+    emb, sp, metas, r = store.file_of("first.md", 3)
+    vs.store_chunks([(f"first:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    stop = threading.Event()
+    stored = []
+
+    def feeder():
+        f = 0
+        while not stop.is_set() and f < 400:
+            e2, s2, m2, _ = store.file_of(f"bg{f}.md", 2)
+            vs.store_chunks([(f"bg{f}:{i}", e, m) for i, (e, m) in enumerate(zip(e2, m2))], sparse_vectors=s2)
+            stored.append(f)
+            f += 1
+            time.sleep(0.001)
+
+    t = threading.Thread(target=feeder)
+    t.start()
+    try:
+        time.sleep(0.01)
+        t0 = time.monotonic()
+        hit = vs.search(toy_embed(r[0], r[1])[0].tolist(), limit=1)[0]
+        waited = time.monotonic() - t0
+        assert hit.metadata.file_path == "first.md"
+        assert waited < 1.0 and not stop.is_set() and t.is_alive()   # the feeder is still queueing: the search did not wait for it
+    finally:
+        stop.set()
+        t.join(30)
+    vs.flush()
+    engine.delay = 0.0
+    engine.fail_next = True
+    emb, sp, metas, _ = store.file_of("bad.md", 2)
+    vs.store_chunks([(f"bad:{i}", e, m) for i, (e, m) in enumerate(zip(emb, metas))], sparse_vectors=sp)
+    assert vs.search(toy_embed(r[0], r[1])[0].tolist(), limit=1)[0].metadata.file_path == "first.md"   # no error here
+    with pytest.raises(RuntimeError, match="could not be completed"):
+        vs.flush()
+    assert vs.failed_file_paths() == ["bad.md"]

@@ -13,40 +13,6 @@ from oracle import core as ocore
 from oracle import fusion as ofus
 
 
-class OracleShard:
-    """Test double with the Engine methods ShardedSearcher uses (test infrastructure only)."""
-
-    def __init__(self, x, sparse_rows):
-        self.xh = ocore.cosine_preprocess(x)
-        self.sp = sparse_rows
-
-    def search_dense(self, q, k, flt=None):
-        sc = ocore.dense_scores(ocore.cosine_preprocess(q), self.xh)
-        return [ocore.topk(sc[i], k) for i in range(q.shape[0])]
-
-    def sparse_stats(self, ids):
-        df, n = ocore.document_frequencies(self.sp)
-        return np.array([df.get(int(t), 0) for t in ids], np.int32), n
-
-    def idf(self, n, df):
-        return ocore.idf(n, df)
-
-    def search_sparse(self, ids, w, k, flt=None, weights_given=False):
-        assert weights_given
-        off, idx, val = ocore.to_csr(self.sp)
-        sc = np.full(len(self.sp), -np.inf, np.float32)
-        for r in range(len(self.sp)):
-            acc, hit = np.float32(0), False
-            for j in range(off[r], off[r + 1]):
-                m = np.nonzero(ids == idx[j])[0]
-                if len(m):
-                    acc = np.float32(acc + np.float32(w[m[0]] * val[j]))
-                    hit = True
-            if hit:
-                sc[r] = acc
-        return ocore.topk(sc, k)
-
-
 def _data():
     rng = np.random.default_rng(42)
     n, dim = 301, 32
@@ -65,11 +31,18 @@ def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from oracle_engine import OracleEngine
         from voitta_rag_amd.sharded import ShardedSearcher
 
         x, sp, q, sq = _data()
         mine = np.arange(rank, len(x), world)  # round-robin shard: local row r <-> global r*world+rank
-        s = ShardedSearcher(OracleShard(x[mine], [sp[i] for i in mine]))
+        shard = OracleEngine(x.shape[1])
+        shard.upsert(x[mine], sparse=[sp[i] for i in mine])
+        s = ShardedSearcher(shard)
+        s.replicate_all()  # the shards were filled locally: exchange the term ids once (collection-wide df from here on)
         out = []
         for i in range(len(q)):
             d = s.search_dense(q[i], 10)

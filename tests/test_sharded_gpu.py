@@ -42,6 +42,7 @@ def _gpu_worker(rank, world, port, ret):
               for _ in range(n)]
         e.upsert(x[mine], sparse=[sp[i] for i in mine])
         s = ShardedSearcher(e)
+        s.replicate_all()  # filled locally: one exchange of term ids makes every shard's df table collection-wide
         q = rng.standard_normal((40, dim)).astype(np.float32)
         sq = [((rng.choice(300, size=3, replace=False) * 7 + 1).astype(np.int32), np.ones(3, np.float32)) for _ in range(40)]
         batch_d = s.search_dense_batch(q, 10)       # > 16 queries: the integer-GEMM batched search on every shard
@@ -52,7 +53,8 @@ def _gpu_worker(rank, world, port, ret):
             h = s.search_hybrid(q[i], sq[i][0], sq[i][1], 5, 0.25)
             ok &= np.array_equal(d[0], batch_d[i][0]) and np.array_equal(d[1], batch_d[i][1])
             ok &= all(np.array_equal(a, b) for a, b in zip(h, batch_h[i]))
-        ret[("batch", rank)] = (bool(ok), [(g.tolist(), sc.tolist()) for g, sc in batch_d[:8]])
+        ret[("batch", rank)] = (bool(ok), [(g.tolist(), sc.tolist()) for g, sc in batch_d[:8]],
+                                [(g.tolist(), sc.tolist()) for g, sc, _ in batch_h[:4]])
         e.close()
         store_registry.reset()
     finally:
@@ -82,17 +84,24 @@ def test_two_ranks_with_real_engines_equal_one_oracle_store(gpu, monkeypatch):
     rng = np.random.default_rng(5)
     n, dim = 40000, 128
     x = rng.standard_normal((n, dim)).astype(np.float32)
-    for _ in range(n):
-        rng.choice(300, size=5, replace=False), rng.uniform(0.5, 2.0, size=5)  # (keeps the generator in step)
+    sp = [((rng.choice(300, size=5, replace=False) * 7 + 1).astype(np.int32), rng.uniform(0.5, 2.0, size=5).astype(np.float32))
+          for _ in range(n)]
     q = rng.standard_normal((40, dim)).astype(np.float32)
+    sq = [((rng.choice(300, size=3, replace=False) * 7 + 1).astype(np.int32), np.ones(3, np.float32)) for _ in range(40)]
     sc = ocore.dense_scores(ocore.cosine_preprocess(q[:8]), ocore.cosine_preprocess(x))
+    # the merged HYBRID answers against one oracle over the whole corpus (collection-wide IDF, fusion after the merge)
+    whole = OracleEngine(dim)
+    whole.upsert(x, sparse=sp)
+    want_h = [whole.search_hybrid(q[i], sq[i][0], sq[i][1], 5, 0.25) for i in range(4)]
     for rank in range(world):
         got = ret[("store", rank)]
         assert len(got) == len(want)
         for i, (g, w) in enumerate(zip(got, want)):
             assert g == w, (rank, i)
-        ok, first = ret[("batch", rank)]
+        ok, first, first_h = ret[("batch", rank)]
         assert ok
+        for i in range(4):
+            assert first_h[i][0] == want_h[i][0].tolist() and first_h[i][1] == want_h[i][1].tolist(), (rank, i)
         for i in range(8):  # round-robin sharding: global id == original row
             wr, ws = ocore.topk(sc[i], 10)
             assert first[i][0] == wr.tolist() and first[i][1] == ws.tolist()
@@ -119,6 +128,7 @@ def _rccl_worker(rank, world, port, ret):
         e.upsert(x, sparse=sp)
         s = ShardedSearcher(e)
         assert s.on_device  # nccl: the communication tensors live on the GPU
+        s.replicate_all()   # (one rank: nothing to apply, but the device-side export and both collectives run)
         q = rng.standard_normal((40, dim)).astype(np.float32)
         sq = [((rng.choice(300, size=3, replace=False) * 7 + 1).astype(np.int32), np.ones(3, np.float32)) for _ in range(40)]
         batch_d = s.search_dense_batch(q, 10)

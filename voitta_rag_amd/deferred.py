@@ -23,7 +23,14 @@ waits until every row stored before it is in the engine (read-your-writes, like 
 
 A caller that actually LOOKS at an embedding (indexes it, iterates it, hands it to numpy) gets the numbers: the
 reference then triggers the encode of that file's texts on the spot and the list behaves like the plain
-``list[list[float]]`` it stands for. VOITTA_DEFERRED_INDEXING=0 turns the whole mechanism off."""
+``list[list[float]]`` it stands for.
+
+Failure contract (the reference's upsert raises INSIDE store_chunks, and indexing.py:558-590 commits the file's DB
+row as soon as the call returns): by default — VOITTA_DEFERRED_INDEXING unset or "sync" — only the REFERENCES are
+deferred: ``store_chunks`` itself makes the one fused engine call for its chunks and raises if it fails, exactly
+when the reference's call would. The write-behind queue is opt-in, VOITTA_DEFERRED_INDEXING=1, for a caller that
+calls ``VectorStoreService.flush()`` (and looks at ``failed_file_paths()``) before it commits its bookkeeping.
+VOITTA_DEFERRED_INDEXING=0 turns the whole mechanism off (plain lists of floats)."""
 from __future__ import annotations
 
 import os
@@ -31,8 +38,18 @@ import os
 import numpy as np
 
 
+def _mode() -> str:
+    return os.environ.get("VOITTA_DEFERRED_INDEXING", "sync").strip().lower()
+
+
 def enabled() -> bool:
-    return os.environ.get("VOITTA_DEFERRED_INDEXING", "1") != "0"
+    """embed_texts returns references (token ids) instead of floats."""
+    return _mode() != "0"
+
+
+def write_behind() -> bool:
+    """store_chunks queues the references for the flusher thread instead of making the fused call itself (opt-in)."""
+    return _mode() in ("1", "async", "write-behind")
 
 
 class EmbeddingRef:

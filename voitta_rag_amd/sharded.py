@@ -1,21 +1,25 @@
 """Corpus sharded by document over the GPUs of one node: one process and one engine per GPU,
 ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests) for the only
-exchange step the path has — merging per-shard top-k lists.
+exchange step a query has — merging per-shard top-k lists.
 
 The reference has no distributed code (one Qdrant server, vector_store.py:71); this module is
 the multi-GPU form of VectorStoreService (:233-434 store / delete, :560-697 search, :699-1016 read helpers):
-  dense   every shard scans its own rows -> all_gather of k (global id, score) pairs -> merge
-  sparse  IDF must be collection-wide: all_reduce(sum) of the query terms' document frequencies
-          and of N, weights q_t * idf_t computed once (vr_idf), shards score with given weights
-  hybrid  min-max fusion runs on the MERGED top-3*limit lists (:659-689), never per shard
-  batch   a whole query batch travels in ONE all_gather (and one all_reduce for the sparse statistics of all
-          its queries); with the nccl backend the dense results never leave the device before the collective
-          (Engine.search_dense_keys writes the ranking keys into the tensor RCCL sends)
+  index   no collective on the data path: a chunk is encoded and stored on its owner. Sparse scoring needs the
+          COLLECTION-WIDE document frequencies (Qdrant's Modifier.IDF statistic, :95-99), so after every upsert /
+          before every delete batch the owner exports the rows' term ids (Engine.sparse_row_ids), the shards
+          all_gather them and each applies the others' (Engine.df_apply): every engine's table holds the statistic of
+          all shards ("one all-reduce (sum) of df deltas after each upsert/delete batch" — the ids
+          are 31-bit hashes, so the deltas travel as id lists rather than as a dense vector).
+  query   ONE collective: every shard leaves its ranking keys — (order-preserving f32 score bits << 32 | ~row), the
+          dense list and, for a hybrid query, the sparse list beside it — in one buffer (Engine.search_dense_keys /
+          search_hybrid_keys; with the nccl backend a device tensor the engine writes and RCCL reads), all_gather,
+          then the merge on the engine's own kernel (Engine.merge_keys -> global ids, scores, counts on the host) and,
+          for hybrid, the fusion of the MERGED top-3*limit lists (:659-689; never per shard) on the host threads
+          (fuse_batch). A batch of queries travels the same way in the same single collective.
   store   ShardedVectorStore: the service API, SPMD — every rank makes the same call with the same arguments;
           a chunk lives on rank shard_of(file_path), so store / delete_by_file / count_by_file touch one
           shard and the folder-level calls touch all of them and sum.
-Messages are k * 16 bytes per rank per list — latency-bound, so a hybrid query sends both of its lists in one
-flat all_gather (after the all_reduce of the query terms' statistics).
+Messages are k * 8 bytes per rank per list — latency-bound.
 
 Global row id of local row r on rank p: r * world + p (order-preserving per shard, unique).
 Ties in score resolve to the lower global id.
@@ -28,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import fuse_minmax
+from .engine import VR_FUSION_MINMAX, fuse_batch
 
 
 def shard_of(file_path: str, world: int) -> int:
@@ -36,15 +40,22 @@ def shard_of(file_path: str, world: int) -> int:
     return zlib.crc32(file_path.encode("utf-8")) % world
 
 
-def _ordered_bits(scores: np.ndarray) -> np.ndarray:
-    """f32 -> uint32 whose unsigned order is the float order (the high word of the engine's ranking keys)."""
-    u = np.ascontiguousarray(scores, np.float32).view(np.uint32)
-    return np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+def pack_keys(rows: np.ndarray, scores: np.ndarray, k: int) -> np.ndarray:
+    """(rows, f32 scores) -> k ranking keys as the engine packs them (include/voitta_engine.h), 0-padded."""
+    out = np.zeros(k, np.uint64)
+    n = len(rows)
+    if n:
+        u = np.ascontiguousarray(scores, np.float32).view(np.uint32)
+        bits = np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+        out[:n] = (bits << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(rows, np.uint64))
+    return out
 
 
 class ShardedSearcher:
     def __init__(self, local, rank: int | None = None, world: int | None = None, group=None):
-        """local: an Engine (or anything with search_dense / search_sparse / sparse_stats / idf)."""
+        """local: this rank's Engine (tests: a double with the same methods). Its document-frequency table must hold
+        the collection-wide statistic: call ``replicate_all()`` once on shards that were filled locally, and
+        ``rows_added`` / ``rows_deleting`` for every later change (ShardedVectorStore does)."""
         self.local = local
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
@@ -60,175 +71,113 @@ class ShardedSearcher:
     def owner(self, gid: int) -> tuple[int, int]:
         return int(gid % self.world), int(gid // self.world)
 
-    # ---- collectives ---------------------------------------------------------------------------
-    def _merge(self, rows: np.ndarray, scores: np.ndarray, k: int):
-        """all_gather this rank's (<= k) results, return the global top-k (gids, scores)."""
-        return self._merge_lists([(rows, scores)], k)[0]
+    # ---- index time: collection-wide document frequencies ----------------------------------------
+    def _exchange_ids(self, rows: np.ndarray, sign: int) -> None:
+        """Collective. This rank contributes the term ids of its local ``rows`` (possibly none); every rank applies
+        the ids of all OTHER ranks to its own table with ``sign``."""
+        rows = np.asarray(rows, np.int64).reshape(-1)
+        if len(rows):
+            ids, pts = self.local.sparse_row_ids(rows, device=True) if self.on_device else self.local.sparse_row_ids(rows)
+        else:
+            ids, pts = np.zeros((0, 0), np.int32), 0
+        n_ids = int(ids.numel()) if self.on_device and len(rows) else int(np.asarray(ids).size)
+        head = torch.tensor([n_ids, pts], dtype=torch.int64, device=self.comm_device)
+        heads = torch.empty((self.world, 2), dtype=torch.int64, device=self.comm_device)
+        dist.all_gather_into_tensor(heads.view(-1), head, group=self.group)
+        heads = heads.cpu().numpy()
+        cap = int(heads[:, 0].max())
+        if cap == 0:
+            return
+        mine = torch.full((cap,), -1, dtype=torch.int32, device=self.comm_device)
+        if n_ids:
+            flat = ids.reshape(-1) if self.on_device else torch.from_numpy(np.ascontiguousarray(ids, np.int32).reshape(-1))
+            mine[:n_ids] = flat
+        everyone = torch.empty((self.world, cap), dtype=torch.int32, device=self.comm_device)
+        dist.all_gather_into_tensor(everyone.view(-1), mine, group=self.group)
+        for p in range(self.world):
+            if p == self.rank or (heads[p, 0] == 0 and heads[p, 1] == 0):
+                continue
+            part = everyone[p, : int(heads[p, 0])].contiguous()
+            self.local.df_apply(part if self.on_device else part.numpy(), int(heads[p, 1]), sign)
 
-    def _merge_lists(self, lists, k: int):
-        """One all_gather for several result lists of this rank (each <= k rows): returns the global
-        top-k (gids, scores) of every list. The hybrid search sends its dense and its sparse list together."""
-        n = len(lists)
-        buf = np.full(n * 2 * k, -1, np.int64)
-        for j, (rows, scores) in enumerate(lists):
-            c = len(rows)
-            base = j * 2 * k
-            buf[base:base + c] = self.global_ids(rows)
-            buf[base + k:base + k + c] = scores.astype(np.float32).view(np.int32).astype(np.int64)
-        mine = torch.from_numpy(buf).to(self.comm_device)
-        out = torch.empty(self.world * n * 2 * k, dtype=torch.int64, device=self.comm_device)
-        dist.all_gather_into_tensor(out, mine, group=self.group)
-        allr = out.cpu().numpy().reshape(self.world, n, 2, k)
-        merged = []
-        for j in range(n):
-            gids = allr[:, j, 0, :].reshape(-1)
-            sc = allr[:, j, 1, :].reshape(-1).astype(np.int32).view(np.float32)
-            keep = gids >= 0
-            gids, sc = gids[keep], sc[keep]
-            order = np.lexsort((gids, -sc.astype(np.float64)))[:k]  # score descending, then gid ascending
-            merged.append((gids[order], sc[order]))
-        return merged
+    def rows_added(self, rows) -> None:
+        """Collective, after this rank stored ``rows`` (others pass what THEY stored, possibly nothing)."""
+        self._exchange_ids(rows, +1)
 
-    def _merge_batch(self, gid: torch.Tensor, bits: torch.Tensor, k: int):
-        """gid, bits: [nq, L, k] int64 on the communication device (-1 / 0 in empty slots): this rank's L result
-        lists per query. ONE all_gather for the whole batch; returns (gids, order-preserving score bits), each
-        [nq, L, k] on the host, merged over the ranks: score descending, then global id ascending."""
-        nq, n_lists, _ = gid.shape
-        mine = torch.stack([gid, bits]).contiguous()                       # [2, nq, L, k]
-        flat = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=self.comm_device)
-        dist.all_gather_into_tensor(flat, mine.reshape(-1), group=self.group)
-        out = flat.view((self.world,) + tuple(mine.shape))
-        allg = out[:, 0].permute(1, 2, 0, 3).reshape(nq, n_lists, self.world * k)
-        allb = out[:, 1].permute(1, 2, 0, 3).reshape(nq, n_lists, self.world * k)
-        # empty slots last; then two stable sorts: by global id ascending, by score bits descending
-        allg = torch.where(allg < 0, torch.full_like(allg, torch.iinfo(torch.int64).max), allg)
-        order = torch.sort(allg, dim=-1, stable=True).indices
-        allg, allb = torch.gather(allg, -1, order), torch.gather(allb, -1, order)
-        order = torch.sort(allb, dim=-1, descending=True, stable=True).indices[..., :k]
-        allg, allb = torch.gather(allg, -1, order), torch.gather(allb, -1, order)
-        allg = torch.where(allb == 0, torch.full_like(allg, -1), allg)
-        return allg.cpu().numpy(), allb.cpu().numpy()
+    def rows_deleting(self, rows) -> None:
+        """Collective, BEFORE this rank deletes ``rows`` (their term ids are read from the still-live rows)."""
+        self._exchange_ids(rows, -1)
 
-    @staticmethod
-    def _bits_to_scores(bits: np.ndarray) -> np.ndarray:
-        u = bits.astype(np.uint32)
-        return np.where(u & np.uint32(0x80000000), u ^ np.uint32(0x80000000), ~u).astype(np.uint32).view(np.float32)
+    def replicate_all(self) -> None:
+        """Collective, once, on shards that were filled locally without the exchange above."""
+        n_rows, _ = self.local.count()
+        self._exchange_ids(np.arange(n_rows, dtype=np.int64), +1)
 
-    def global_sparse_weights(self, q_idx, q_val):
-        """q_t * idf_t from all-reduced statistics -> (ids sorted unique, weights f32)."""
-        return self.global_sparse_weights_batch([(q_idx, q_val)])[0]
+    # ---- the one collective of a query ------------------------------------------------------------
+    def _gather_and_merge(self, keys, n_lists: int, k: int):
+        """keys: this rank's n_lists x k packed keys (uint64 NumPy array, or int64 device tensor with nccl).
+        -> (global ids [n_lists, k] (-1 padded), scores f32 [n_lists, k], counts [n_lists]) merged over the ranks:
+        all_gather, then the merge on the engine (Engine.merge_keys) and one copy to the host."""
+        if self.on_device:
+            mine = keys if hasattr(keys, "is_cuda") else torch.from_numpy(np.ascontiguousarray(keys).view(np.int64)).to(self.comm_device)
+            parts = torch.empty((self.world, n_lists, k), dtype=torch.int64, device=self.comm_device)
+            dist.all_gather_into_tensor(parts.view(-1), mine.reshape(-1), group=self.group)
+            return self.local.merge_keys(parts, k)
+        mine = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64).reshape(-1))
+        parts = torch.empty(self.world * n_lists * k, dtype=torch.int64)
+        dist.all_gather_into_tensor(parts, mine, group=self.group)
+        return self.local.merge_keys(parts.numpy().view(np.uint64).reshape(self.world, n_lists, k), k)
 
-    def global_sparse_weights_batch(self, queries):
-        """The same for a batch of sparse queries with ONE all_reduce: the document frequencies of every query's
-        terms and the point count N travel together."""
-        uniq = []
-        for q_idx, q_val in queries:
-            pairs = {}
-            for i, v in zip(np.asarray(q_idx, np.int64).reshape(-1).tolist(), np.asarray(q_val, np.float32).reshape(-1).tolist()):
-                pairs.setdefault(int(i), np.float32(v))
-            uniq.append(pairs)
-        all_ids = np.array([t for pairs in uniq for t in sorted(pairs)], np.int32)
-        df, n_points = self.local.sparse_stats(all_ids)
-        stat = torch.from_numpy(np.concatenate([np.asarray(df, np.int64), [n_points]])).to(self.comm_device)
-        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=self.group)
-        stat = stat.cpu().numpy()
-        n_all = int(stat[-1])
-        out, at = [], 0
-        for pairs in uniq:
-            ids = np.array(sorted(pairs), np.int32)
-            w = np.array([np.float32(pairs[int(t)]) * np.float32(self.local.idf(n_all, int(d)))
-                          for t, d in zip(ids, stat[at:at + len(ids)])], np.float32)
-            at += len(ids)
-            out.append((ids, w))
-        return out
+    def _dense_keys(self, queries, k: int, flt):
+        nq = int(queries.shape[0])
+        if self.on_device:
+            q = queries if hasattr(queries, "is_cuda") else torch.from_numpy(np.ascontiguousarray(queries, np.float32)).to(self.comm_device)
+            return self.local.search_dense_keys(q.contiguous(), k, flt, out=torch.empty((nq, k), dtype=torch.int64, device=self.comm_device))
+        return self.local.search_dense_keys(np.asarray(queries, np.float32).reshape(nq, -1), k, flt)
+
+    def _hybrid_keys(self, queries, sparse_queries, k: int, flt):
+        nq = int(queries.shape[0])
+        if self.on_device:
+            q = queries if hasattr(queries, "is_cuda") else torch.from_numpy(np.ascontiguousarray(queries, np.float32)).to(self.comm_device)
+            return self.local.search_hybrid_keys(q.contiguous(), sparse_queries, k, flt,
+                                                 out=torch.empty((nq, 2, k), dtype=torch.int64, device=self.comm_device))
+        return self.local.search_hybrid_keys(np.asarray(queries, np.float32).reshape(nq, -1), sparse_queries, k, flt)
 
     # ---- searches ------------------------------------------------------------------------------
     def search_dense(self, query, k: int, flt=None):
-        rows, scores = self.local.search_dense(np.asarray(query, np.float32).reshape(1, -1), k, flt)[0]
-        return self._merge(rows, scores, k)
-
-    def search_sparse(self, q_idx, q_val, k: int, flt=None):
-        ids, w = self.global_sparse_weights(q_idx, q_val)
-        if len(ids) == 0:
-            return np.zeros(0, np.int64), np.zeros(0, np.float32)
-        rows, scores = self.local.search_sparse(ids, w, k, flt, weights_given=True)
-        return self._merge(rows, scores, k)
-
-    def search_hybrid(self, query, q_idx, q_val, limit: int, sparse_weight: float = 0.1, flt=None):
-        """-> (gids, fused scores f64, from_dense) exactly as one engine holding every shard would.
-        Two collectives per query: the all_reduce of the query terms' statistics, then ONE all_gather that
-        carries this shard's dense and sparse lists together."""
-        k = 3 * limit  # prefetch_limit, vector_store.py:636
-        empty = (np.zeros(0, np.int64), np.zeros(0, np.float32))
-        d_local = self.local.search_dense(np.asarray(query, np.float32).reshape(1, -1), k, flt)[0]
-        s_local = empty
-        have_sparse = len(np.atleast_1d(q_idx)) > 0
-        if have_sparse:
-            ids, w = self.global_sparse_weights(q_idx, q_val)
-            if len(ids):
-                s_local = self.local.search_sparse(ids, w, k, flt, weights_given=True)
-        if have_sparse:
-            (d_ids, d_sc), (s_ids, s_sc) = self._merge_lists([d_local, s_local], k)
-        else:
-            (d_ids, d_sc), (s_ids, s_sc) = self._merge_lists([d_local], k)[0], empty
-        return fuse_minmax(d_ids, d_sc, s_ids, s_sc, limit, sparse_weight, True)
-
-    # ---- batches: one all_gather per batch --------------------------------------------------------
-    def _local_dense_batch(self, queries, k: int, flt):
-        """-> (gid, bits) [nq, k] int64 tensors on the communication device for this shard's dense results."""
-        nq = int(queries.shape[0])
-        if self.on_device and hasattr(self.local, "search_dense_keys"):
-            # the engine writes its ranking keys straight into the tensor the collective will read
-            q = queries if hasattr(queries, "is_cuda") else torch.from_numpy(np.ascontiguousarray(queries, np.float32)).to(self.comm_device)
-            keys = torch.empty((nq, k), dtype=torch.int64, device=self.comm_device)
-            self.local.search_dense_keys(q.contiguous(), k, flt, out=keys)
-            rows = 0xFFFFFFFF - (keys & 0xFFFFFFFF)
-            bits = (keys >> 32) & 0xFFFFFFFF
-            gid = torch.where(keys == 0, torch.full_like(rows, -1), rows * self.world + self.rank)
-            return gid, torch.where(keys == 0, torch.zeros_like(bits), bits)
-        res = self.local.search_dense(np.asarray(queries, np.float32).reshape(nq, -1), k, flt)
-        gid = np.full((nq, k), -1, np.int64)
-        bits = np.zeros((nq, k), np.int64)
-        for i, (rows, scores) in enumerate(res):
-            gid[i, :len(rows)] = self.global_ids(rows)
-            bits[i, :len(rows)] = _ordered_bits(scores)
-        return torch.from_numpy(gid).to(self.comm_device), torch.from_numpy(bits).to(self.comm_device)
+        return self.search_dense_batch(np.asarray(query, np.float32).reshape(1, -1), k, flt)[0]
 
     def search_dense_batch(self, queries, k: int, flt=None):
         """queries: (nq, D). -> list of (gids, scores) per query, merged over the shards; ONE all_gather."""
-        gid, bits = self._local_dense_batch(queries, k, flt)
-        g, b = self._merge_batch(gid[:, None, :], bits[:, None, :], k)
-        out = []
-        for i in range(g.shape[0]):
-            keep = g[i, 0] >= 0
-            out.append((g[i, 0][keep], self._bits_to_scores(b[i, 0][keep])))
-        return out
+        nq = int(queries.shape[0])
+        gid, sc, cnt = self._gather_and_merge(self._dense_keys(queries, k, flt), nq, k)
+        return [(gid[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(nq)]
 
-    def search_hybrid_batch(self, queries, sparse_queries, limit: int, sparse_weight: float = 0.1, flt=None):
-        """Hybrid search of a query batch: one all_reduce (statistics of every query's terms), one all_gather (every
-        query's dense and sparse list). -> list of (gids, fused f64 scores, from_dense) per query."""
-        k = 3 * limit
+    def search_sparse(self, q_idx, q_val, k: int, flt=None):
+        """One sparse query (collection-wide IDF from the local table) -> (gids, scores)."""
+        rows, scores = self.local.search_sparse_batch([(q_idx, q_val)], k, flt)[0]
+        gid, sc, cnt = self._gather_and_merge(pack_keys(rows, scores, k).reshape(1, k), 1, k)
+        return gid[0, : cnt[0]].copy(), sc[0, : cnt[0]].copy()
+
+    def search_hybrid(self, query, q_idx, q_val, limit: int, sparse_weight: float = 0.1, flt=None,
+                      fusion: int = VR_FUSION_MINMAX):
+        """-> (gids, fused scores f64, from_dense) exactly as one engine holding every shard would. ONE collective:
+        the all_gather that carries this shard's dense and sparse keys together."""
+        sq = (q_idx, q_val) if len(np.atleast_1d(q_idx)) > 0 else None
+        return self.search_hybrid_batch(np.asarray(query, np.float32).reshape(1, -1), [sq], limit, sparse_weight, flt, fusion)[0]
+
+    def search_hybrid_batch(self, queries, sparse_queries, limit: int, sparse_weight: float = 0.1, flt=None,
+                            fusion: int = VR_FUSION_MINMAX):
+        """Hybrid search of a query batch: every query's dense and sparse list in ONE all_gather, merged on the engine,
+        fused on the host threads. -> list of (gids, fused f64 scores, from_dense) per query."""
+        k = 3 * limit  # prefetch_limit, vector_store.py:636
         nq = int(queries.shape[0])
         assert len(sparse_queries) == nq
-        d_gid, d_bits = self._local_dense_batch(queries, k, flt)
-        weights = self.global_sparse_weights_batch(sparse_queries)
-        s_gid = np.full((nq, k), -1, np.int64)
-        s_bits = np.zeros((nq, k), np.int64)
-        for i, (ids, w) in enumerate(weights):
-            if len(ids) == 0:
-                continue
-            rows, scores = self.local.search_sparse(ids, w, k, flt, weights_given=True)
-            s_gid[i, :len(rows)] = self.global_ids(rows)
-            s_bits[i, :len(rows)] = _ordered_bits(scores)
-        gid = torch.stack([d_gid, torch.from_numpy(s_gid).to(self.comm_device)], dim=1)
-        bits = torch.stack([d_bits, torch.from_numpy(s_bits).to(self.comm_device)], dim=1)
-        g, b = self._merge_batch(gid, bits, k)
-        out = []
-        for i in range(nq):
-            dk, sk = g[i, 0] >= 0, g[i, 1] >= 0
-            out.append(fuse_minmax(g[i, 0][dk], self._bits_to_scores(b[i, 0][dk]), g[i, 1][sk],
-                                   self._bits_to_scores(b[i, 1][sk]), limit, sparse_weight, True))
-        return out
+        gid, sc, cnt = self._gather_and_merge(self._hybrid_keys(queries, sparse_queries, k, flt), 2 * nq, k)
+        gid, sc, cnt = gid.reshape(nq, 2, k), sc.reshape(nq, 2, k), cnt.reshape(nq, 2)
+        rows, fused, fd, n = fuse_batch(gid[:, 0], sc[:, 0], cnt[:, 0], gid[:, 1], sc[:, 1], cnt[:, 1], limit, sparse_weight,
+                                        fusion, True)
+        return [(rows[i, : n[i]].copy(), fused[i, : n[i]].copy(), fd[i, : n[i]].copy()) for i in range(nq)]
 
 
 class ShardedVectorStore:
@@ -269,7 +218,8 @@ class ShardedVectorStore:
     # ---- store / delete / ACL ----------------------------------------------------------------------
     def store_chunks(self, chunks, sparse_vectors=None, batch_size: int = 100) -> list[str]:
         """Every rank passes the full batch; each keeps the chunks of the files it owns. Returns the point ids in
-        the order of ``chunks`` (vector_store.py:233-317), identical on every rank."""
+        the order of ``chunks`` (vector_store.py:233-317), identical on every rank. The new rows' term ids are
+        exchanged before the call returns, so every shard's document frequencies stay collection-wide."""
         if not chunks:
             return []
         keep = [i for i, c in enumerate(chunks) if self._mine(c[2].file_path)]
@@ -277,20 +227,39 @@ class ShardedVectorStore:
         if sparse_vectors:
             sv = [sparse_vectors[i] if i < len(sparse_vectors) else ([], []) for i in keep]
         mine = self.local.store_chunks([chunks[i] for i in keep], sparse_vectors=sv, batch_size=batch_size) if keep else []
+        col = self.local._col
+        self.local._drain(col)  # (write-behind: the rows must be in the engine before their term ids can be read)
+        with col.lock:
+            rows = [col.row_of[pid] for pid in mine]
+        self.searcher.rows_added(np.asarray(rows, np.int64))
         ids: list = [None] * len(chunks)
         for part in self._gather(list(zip(keep, mine))):
             for i, pid in part:
                 ids[i] = pid
         return ids
 
+    def _delete(self, select, delete) -> int:
+        """select(col) -> this rank's candidate rows; their statistics leave every OTHER shard's table first, then
+        the owner deletes (which takes them out of its own). SPMD: mutations are made by one thread per rank."""
+        col = self.local._col
+        self.local._drain(col)
+        with col.lock:
+            rows = [r for r in select(col) if col.payload[r] is not None]
+        self.searcher.rows_deleting(np.asarray(rows, np.int64))
+        return self._sum(delete() if rows else 0)[0]
+
     def delete_by_file(self, file_path: str) -> int:
-        return self._sum(self.local.delete_by_file(file_path) if self._mine(file_path) else 0)[0]
+        mine = self._mine(file_path)
+        return self._delete(lambda col: list(col.rows_by_file.get(file_path, [])) if mine else [],
+                            lambda: self.local.delete_by_file(file_path))
 
     def delete_by_folder(self, folder_path: str) -> int:
-        return self._sum(self.local.delete_by_folder(folder_path))[0]
+        return self._delete(lambda col: [r for r in col.live_rows() if col.payload[r]["folder_path"] == folder_path],
+                            lambda: self.local.delete_by_folder(folder_path))
 
     def delete_by_index_folder(self, index_folder: str) -> int:
-        return self._sum(self.local.delete_by_index_folder(index_folder))[0]
+        return self._delete(lambda col: [r for r in col.live_rows() if col.payload[r].get("index_folder") == index_folder],
+                            lambda: self.local.delete_by_index_folder(index_folder))
 
     def set_file_acl(self, file_path: str, allowed_users: list[str]) -> None:
         if self._mine(file_path):
@@ -301,16 +270,23 @@ class ShardedVectorStore:
     def search(self, query_embedding, limit: int = 10, folder_filter=None, include_folders=None, exclude_folders=None,
                exclude_index_folders=None, sparse_query=None, sparse_weight: float = 0.1, date_start=None,
                date_end=None, date_field=None):
-        """VectorStoreService.search over every shard: the merged lists are fused once (vector_store.py:659-689),
-        then the owners of the winners contribute their payloads (one more small collective)."""
+        """VectorStoreService.search over every shard: ONE collective for the lists (merged, then fused once:
+        vector_store.py:659-689), then the owners of the winners contribute their payloads (a second small one).
+        The table lock is held for the filter and for the row -> payload mapping only, never across a collective; a
+        rank whose table changed meanwhile (a delete or a compaction on another thread) says so in the payload
+        exchange and every rank searches again."""
         if limit <= 0:
             return []
         col = self.local._col
+        self.local._drain(col, surface_errors=False)
         q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
-        with col.lock:
-            flt = self.local._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
-                                           date_start=date_start, date_end=date_end, date_field=date_field)
-            hybrid = bool(sparse_query and self.local._has_sparse and len(sparse_query[0]) > 0)
+        hybrid = bool(sparse_query and self.local._has_sparse and len(sparse_query[0]) > 0)
+        engine = self.local._engine
+        for _attempt in range(16):
+            with col.lock:
+                flt = self.local._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
+                                               date_start=date_start, date_end=date_end, date_field=date_field)
+                version, generation = col.version, col.generation
             if hybrid:
                 gids, scores, _ = self.searcher.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight, flt)
                 scores = [float(s) for s in scores]
@@ -318,14 +294,22 @@ class ShardedVectorStore:
                 gids, sc = self.searcher.search_dense(q, limit, flt)
                 scores = [float(str(np.float32(s))) for s in sc]  # the REST/JSON transport of a dense score [EXT]
             mine = {}
-            for gid in gids.tolist():
-                p, row = self.searcher.owner(gid)
-                if p == self.rank:
-                    mine[gid] = (col.ids[row], col.payload[row])
-        found = {}
-        for part in self._gather(mine):
-            found.update(part)
-        return [self.local._chunk_from(found[g][0], found[g][1], s) for g, s in zip(gids.tolist(), scores)]
+            with col.lock:
+                stale = col.version != version or (hasattr(engine, "generation") and not engine.generation() == col.generation == generation)
+                if not stale:
+                    for gid in gids.tolist():
+                        p, row = self.searcher.owner(gid)
+                        if p == self.rank:
+                            mine[gid] = (col.ids[row], col.payload[row])
+            parts = self._gather((stale, mine))
+            if any(st for st, _ in parts):
+                continue
+            found = {}
+            for _, part in parts:
+                found.update(part)
+            return [self.local._chunk_from(found[g][0], found[g][1], s) for g, s in zip(gids.tolist(), scores)
+                    if found.get(g, (None, None))[1] is not None]
+        raise RuntimeError("sharded search: the collection kept changing")
 
     # ---- read helpers --------------------------------------------------------------------------------
     def get_collection_info(self) -> dict:

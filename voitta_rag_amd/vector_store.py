@@ -89,7 +89,10 @@ class _Collection:
         self.pending: list[dict] = []
         self.pending_rows = 0
         self.flushing = False
-        self.drain_waiters = 0
+        self.enq_seq = 0       # sequence number of the last store queued
+        self.done_seq = 0      # ... of the last store the flusher has finished with (stored, or dropped after a failure)
+        self.drain_target = 0  # the highest sequence number some caller is waiting for
+        self.failed_files: set[str] = set()  # files whose queued rows a failed fused call took back (failed_file_paths)
         self.flusher: threading.Thread | None = None
         self.stopped = False
         self.deferred_error: BaseException | None = None
@@ -475,7 +478,15 @@ class VectorStoreService:
         if _deferred.enabled():
             taken = _deferred.take_deferred(chunks, sparse_vectors)
             if taken is not None and chunks[0][1].batch.encoder.engine is self._engine and chunks[0][1].batch.dim == self.dimension:
-                return self._store_deferred(col, chunks, *taken)
+                if _deferred.write_behind():
+                    return self._store_deferred(col, chunks, *taken)
+                # the default: the embeddings were never looked at, so they never became Python floats — ONE fused
+                # engine call (encode -> BM25 tf -> append) made HERE, failing here if it fails (the reference's
+                # upsert raises inside store_chunks and the caller marks the file failed: indexing.py:558-590)
+                wp_ids, wp_off, bm_ids, bm_off = taken
+                return self.index_chunks([c[0] for c in chunks], [c[2] for c in chunks], np.asarray(wp_ids, np.int32),
+                                         np.asarray(wp_off, np.int32), None if bm_off is None else np.asarray(bm_ids, np.int32),
+                                         None if bm_off is None else np.asarray(bm_off, np.int64))
         dense = np.asarray([c[1] for c in chunks], dtype=np.float32).reshape(n, self.dimension)
         ids = [str(uuid.uuid4()) for _ in chunks]  # :256
         payloads = [self._payload_of(text, metadata) for text, _emb, metadata in chunks]
@@ -537,7 +548,8 @@ class VectorStoreService:
                 with col.lock:
                     folder = np.array([col.folder_id(c[2].folder_path, True) for c in chunks], np.int32)
                     ifolder = np.array([col.index_folder_id(c[2].index_folder, True) for c in chunks], np.int32)
-                entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(),
+                col.enq_seq += 1
+                entry = dict(engine=self._engine, first=first, n=n, ids=ids, payloads=payloads, t=time.monotonic(), seq=col.enq_seq,
                              wp_ids=np.asarray(wp_ids, np.int32), wp_off=np.asarray(wp_off, np.int64),
                              bm_ids=None if bm_off is None else np.asarray(bm_ids, np.int32),  # None: a dense-only store
                              bm_off=None if bm_off is None else np.asarray(bm_off, np.int64),
@@ -556,7 +568,7 @@ class VectorStoreService:
         while True:
             with col.pending_cv:
                 while not col.stopped:
-                    if col.pending and (col.pending_rows >= cls._FLUSH_ROWS or col.drain_waiters
+                    if col.pending and (col.pending_rows >= cls._FLUSH_ROWS or col.pending[0]["seq"] <= col.drain_target
                                         or time.monotonic() - col.pending[0]["t"] >= cls._FLUSH_LINGER_S):
                         break
                     col.pending_cv.wait(cls._FLUSH_LINGER_S if col.pending else None)
@@ -576,13 +588,17 @@ class VectorStoreService:
                     for b in reversed(batch + later):  # rows that did not reach the engine: taken back, newest first
                         if not b.get("done"):
                             cls._drop_host_rows(col, b["first"], b["ids"], b["payloads"])
+                            col.failed_files.update(p["file_path"] for p in b["payloads"])
                 finally:
                     with col.pending_cv:
                         col.recovering = False
+                        if later:
+                            col.done_seq = max(col.done_seq, later[-1]["seq"])
                         col.pending_cv.notify_all()
             finally:
                 with col.pending_cv:
                     col.flushing = False
+                    col.done_seq = max(col.done_seq, batch[-1]["seq"])
                     col.pending_cv.notify_all()
 
     @staticmethod
@@ -625,23 +641,38 @@ class VectorStoreService:
         if err is not None:
             raise RuntimeError("an earlier store_chunks could not be completed by the engine; its rows were dropped") from err
 
-    def _drain(self, col: _Collection) -> None:
-        """Returns when every store_chunks that returned before this call is in the engine (read-your-writes)."""
+    def _drain(self, col: _Collection, surface_errors: bool = True) -> None:
+        """Returns when every store_chunks that returned BEFORE this call is in the engine (read-your-writes): the
+        queue entries carry sequence numbers and the wait ends when the flusher has finished with the last one that
+        was queued on entry — stores queued meanwhile by an indexing thread are not waited for.
+        surface_errors=False (search): a failed background store is not this caller's error; it stays recorded for
+        the next store_chunks / flush / delete."""
         if col.flusher is None:
             return
         with col.pending_cv:
-            if col.pending or col.flushing:
-                col.drain_waiters += 1
+            target = col.enq_seq
+            if col.done_seq < target:
+                col.drain_target = max(col.drain_target, target)
                 col.pending_cv.notify_all()
-                try:
-                    while (col.pending or col.flushing) and not col.stopped:
-                        col.pending_cv.wait(0.5)
-                finally:
-                    col.drain_waiters -= 1
-        self._raise_deferred_error(col)
+                while col.done_seq < target and not col.stopped:
+                    col.pending_cv.wait(0.5)
+        if surface_errors:
+            self._raise_deferred_error(col)
+
+    def failed_file_paths(self, clear: bool = True) -> list[str]:
+        """Write-behind only (VOITTA_DEFERRED_INDEXING=1): files whose rows a failed fused store took back out of the
+        table after their store_chunks had returned. A caller that keeps its own bookkeeping (the reference commits an
+        IndexedFile row per file, indexing.py:558-590) calls flush() and then this before it commits."""
+        col = self._col
+        with col.pending_cv:
+            out = sorted(col.failed_files)
+            if clear:
+                col.failed_files.clear()
+        return out
 
     def flush(self) -> None:
-        """Wait until everything stored so far is searchable (it becomes so by itself within a few ms)."""
+        """Wait until everything stored so far is searchable (it becomes so by itself within a few ms); raises if a
+        queued store failed since the last call (see failed_file_paths)."""
         self._drain(self._col)
 
     @staticmethod
@@ -768,7 +799,7 @@ class VectorStoreService:
         if limit <= 0:
             return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
-        self._drain(col)
+        self._drain(col, surface_errors=False)
         kept = getattr(query_embedding, "array", None) if isinstance(query_embedding, _deferred.QueryEmbedding) else None
         if (kept is not None and len(query_embedding) == kept.size == self.dimension
                 and query_embedding[0] == float(kept[0]) and query_embedding[-1] == float(kept[-1])):  # (not edited since)
@@ -776,31 +807,102 @@ class VectorStoreService:
         else:
             q = np.asarray(query_embedding, dtype=np.float32).reshape(self.dimension)
         hybrid = bool(sparse_query and self._has_sparse and sparse_query[0])
-        for attempt in range(64):
+
+        def run(search_filter):
+            if hybrid:
+                rows, scores, _ = self._engine.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight,
+                                                            flt=search_filter)
+                return rows, [float(s) for s in scores]
+            rows, scores = self._engine.search_dense(q[None, :], limit, search_filter)[0]
+            return rows, [_json_float(s) for s in scores]
+
+        rows, scores = self._search_consistent(col, run, folder_filter, include_folders, exclude_folders, exclude_index_folders,
+                                               date_start, date_end, date_field)
+        return [self._chunk_from(pid, payload, s) for (pid, payload), s in zip(rows, scores) if payload is not None]
+
+    _SEARCH_DEADLINE_S = float(os.environ.get("VOITTA_SEARCH_DEADLINE_S", "30"))
+
+    def _search_consistent(self, col: _Collection, run, folder_filter, include_folders, exclude_folders, exclude_index_folders,
+                           date_start, date_end, date_field):
+        """Runs ``run(filter) -> (rows, extra)`` against a consistent pair of engine state and host table and returns
+        ([(point id, payload)] for the rows, extra). The engine call holds no Python lock (searches of several threads
+        run side by side on the engine's lanes); a delete or a compaction that finished meanwhile (rows gone or
+        renumbered) makes the search look again — its answer then belongs to the later state. While a compaction has
+        swapped the engine's tables and the host table has not followed yet, the search WAITS (the old index is being
+        freed: tens of milliseconds at millions of rows) — up to a deadline of seconds, after which it raises rather
+        than return nothing or map rows through a table of another numbering."""
+        deadline = time.monotonic() + self._SEARCH_DEADLINE_S
+        has_generation = hasattr(self._engine, "generation")
+        while True:
             with col.lock:
                 search_filter = self._build_filter(folder_filter, include_folders, exclude_folders, exclude_index_folders,
                                                    date_start=date_start, date_end=date_end, date_field=date_field)
                 version, generation = col.version, col.generation
-            # the engine call holds no Python lock: searches of several threads run side by side on the engine's lanes
-            if hasattr(self._engine, "generation") and self._engine.generation() != generation:
-                time.sleep(0.0005)  # a compaction has swapped the engine's tables, the host table follows in a moment
+            if has_generation and self._engine.generation() != generation:
+                if time.monotonic() > deadline:
+                    raise RuntimeError("search: the host table did not catch up with the engine's compaction "
+                                       f"within {self._SEARCH_DEADLINE_S:.0f} s")
+                time.sleep(0.0005)
                 continue
-            if hybrid:
-                rows, scores, _ = self._engine.search_hybrid(q, sparse_query[0], sparse_query[1], limit, sparse_weight,
-                                                            flt=search_filter)
-                scores = [float(s) for s in scores]
-            else:
-                rows, scores = self._engine.search_dense(q[None, :], limit, search_filter)[0]
-                scores = [_json_float(s) for s in scores]
+            rows, extra = run(search_filter)
             with col.lock:
-                # rows -> payloads, unless a delete or a compaction finished meanwhile (the rows might be gone or
-                # renumbered): then look again — the new answer belongs to the state after that mutation
-                unchanged = col.version == version and (not hasattr(self._engine, "generation")
+                unchanged = col.version == version and (not has_generation
                                                         or self._engine.generation() == col.generation == generation)
-                if unchanged or attempt == 63:
-                    return [self._chunk_from(col.ids[r], col.payload[r], s) for r, s in zip(rows, scores)
-                            if r < len(col.payload) and col.payload[r] is not None]
-        return []
+                if unchanged:
+                    flat = np.asarray(rows).reshape(-1).tolist()
+                    return [(col.ids[r], col.payload[r]) if 0 <= r < len(col.payload) else (None, None) for r in flat], extra
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"search: the collection kept changing for {self._SEARCH_DEADLINE_S:.0f} s")
+
+    def search_many(self, query_embeddings, limit: int = 10, folder_filter: str | None = None,
+                    include_folders: list[str] | None = None, exclude_folders: list[str] | None = None,
+                    exclude_index_folders: list[str] | None = None, sparse_queries=None, sparse_weight: float = 0.1,
+                    date_start: int | None = None, date_end: int | None = None,
+                    date_field: str | None = None) -> list[list[StoredChunk]]:
+        """``search`` for MANY queries in one engine call (BASELINE configs[4]: 1k batched queries; the MCP search tool
+        under load, mcp_server.py:469-485): query_embeddings is (nq, D), sparse_queries a list of (indices, values)
+        per query or None. Result i is what ``search(query_embeddings[i], ..., sparse_query=sparse_queries[i])``
+        returns — same branch selection per query (vector_store.py:560-619: hybrid only with sparse terms), same
+        filters, same scores — but the dense legs share one batched scan, the sparse legs one launch over the inverted
+        index, and the fusion of every query runs on the host threads (vr_search_hybrid_batch)."""
+        q = np.ascontiguousarray(np.asarray(query_embeddings, dtype=np.float32).reshape(-1, self.dimension))
+        nq = q.shape[0]
+        if limit <= 0 or nq == 0:
+            return [[] for _ in range(nq)]
+        col = self._col
+        self._drain(col, surface_errors=False)
+        sq = list(sparse_queries) if sparse_queries is not None and self._has_sparse else [None] * nq
+        assert len(sq) == nq
+        sq = [s if s is not None and len(s[0]) > 0 else None for s in sq]
+        any_hybrid = any(s is not None for s in sq)
+
+        def run(search_filter):
+            if any_hybrid:
+                rows, scores, _fd, counts = self._engine.search_hybrid_batch(q, sq, limit, sparse_weight, flt=search_filter, raw=True)
+            else:
+                rows, scores, counts = np.full((nq, limit), -1, np.int64), np.zeros((nq, limit)), np.zeros(nq, np.int32)
+            # a query without sparse terms takes the dense-only branch (:612-617): `limit` results, raw cosine scores
+            dense_only = [i for i in range(nq) if sq[i] is None]
+            out_scores = [[float(s) for s in scores[i, : counts[i]]] for i in range(nq)]
+            if dense_only:
+                res = self._engine.search_dense(q[dense_only], limit, search_filter)
+                for i, (r, s) in zip(dense_only, res):
+                    counts[i] = len(r)
+                    rows[i, : len(r)] = r
+                    rows[i, len(r):] = -1
+                    out_scores[i] = [_json_float(v) for v in s]
+            for i in range(nq):
+                rows[i, counts[i]:] = -1
+            return rows, (counts.copy(), out_scores)
+
+        pairs, (counts, scores) = self._search_consistent(col, run, folder_filter, include_folders, exclude_folders,
+                                                          exclude_index_folders, date_start, date_end, date_field)
+        out = []
+        for i in range(nq):
+            base = i * limit
+            out.append([self._chunk_from(pid, payload, s) for (pid, payload), s in zip(pairs[base: base + int(counts[i])], scores[i])
+                        if payload is not None])
+        return out
 
     # ---- read helpers (payload only) ---------------------------------------------------------------
     def find_by_source_url(self, source_url: str) -> list[StoredChunk]:
