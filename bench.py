@@ -63,6 +63,9 @@ def parse():
                         "is also measured on (0 = skip; single GPU only)")
     p.add_argument("--dropin-files", type=int, default=2000,
                    help="synthetic documents pushed through the reference's unmodified per-file call sequence (0 = skip)")
+    p.add_argument("--other-rows", type=int, default=1_000_000,
+                   help="rows of the dense corpora the OTHER model widths (MiniLM 384, bge-large 1024) are searched on, after a "
+                        "short indexing run with each shape (0 = skip; single GPU only)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16"],
@@ -106,14 +109,15 @@ def make_batch(torch, gen, dev, n_chunks, seed_shift):
     return wp.contiguous(), wp_off.contiguous(), bm.contiguous(), bm_off.contiguous(), T
 
 
-def random_state(torch, gen, dev):
+def random_state(torch, gen, dev, model=None):
     from voitta_rag_amd import encoder as enc
 
-    H, I = MODEL["hidden"], MODEL["intermediate"]
+    model = model or MODEL
+    H, I = model["hidden"], model["intermediate"]
     state = {}
-    for n in enc.tensor_names(MODEL["layers"]):
-        if n.endswith("word_embeddings.weight"): shp = (MODEL["vocab"], H)
-        elif n.endswith("position_embeddings.weight"): shp = (MODEL["max_pos"], H)
+    for n in enc.tensor_names(model["layers"]):
+        if n.endswith("word_embeddings.weight"): shp = (model["vocab"], H)
+        elif n.endswith("position_embeddings.weight"): shp = (model["max_pos"], H)
         elif n.endswith("token_type_embeddings.weight"): shp = (2, H)
         elif n.endswith("intermediate.dense.weight"): shp = (I, H)
         elif n.endswith("intermediate.dense.bias"): shp = (I,)
@@ -257,6 +261,19 @@ def dropin_section(args, engine, state, rng):
         vs.store_chunks(chunk_data, sparse_vectors=sparse_vectors)
         return len(chunks)
 
+    # default mode of the drop-in (VOITTA_DEFERRED_INDEXING unset): store_chunks makes its one fused call itself and
+    # fails where the reference's upsert fails; timed on a tenth of the files
+    os.environ.pop("VOITTA_DEFERRED_INDEXING", None)
+    n_sync = max(20, args.dropin_files // 10)
+    for i in range(20):
+        index_file(10_000_000 + i, docs[i])
+    engine.sync()
+    t0 = time.perf_counter()
+    sync_chunks = sum(index_file(20_000_000 + i, docs[40 + i]) for i in range(n_sync))
+    engine.sync()
+    sync_rate = sync_chunks / (time.perf_counter() - t0)
+    # the opt-in write-behind (VOITTA_DEFERRED_INDEXING=1: a caller that calls flush() before it commits its bookkeeping)
+    os.environ["VOITTA_DEFERRED_INDEXING"] = "1"
     for i in range(40):  # warm-up: flusher thread, table growth, graphs
         index_file(i, docs[i])
     vs.flush()
@@ -266,6 +283,8 @@ def dropin_section(args, engine, state, rng):
     vs.flush()  # every row searchable
     engine.sync()
     dt = time.perf_counter() - t0
+    assert vs.failed_file_paths() == []
+    os.environ.pop("VOITTA_DEFERRED_INDEXING", None)
 
     warr = np.array(words)
     questions = [" ".join(warr[rng.integers(0, len(warr), size=int(rng.integers(5, 12)))]) + "?" for _ in range(220)]
@@ -277,7 +296,8 @@ def dropin_section(args, engine, state, rng):
             lat[i - 20] = time.perf_counter() - t1
         assert len(got) == 10
     store_registry.set_engine(None)  # (the engine stays ours to close)
-    return n_chunks / dt, n_chunks, args.dropin_files, float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3)
+    return (n_chunks / dt, n_chunks, args.dropin_files, float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3),
+            sync_rate, n_sync)
 
 
 def anisotropic_section(args, torch, dev, dim):
@@ -321,6 +341,73 @@ def anisotropic_section(args, torch, dev, dim):
            "candidates_median": int(np.median(cand)), "candidates_max": int(cand.max()),
            "fallbacks": s1["fallback"] - s0["fallback"],
            "qps_batched": round(args.queries / dt, 1), "batched_fallbacks": s2["batch_fallback"] - s1["batch_fallback"]}
+    e.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+OTHER_MODELS = [
+    dict(name="all-MiniLM-L6-v2", layers=6, hidden=384, heads=12, intermediate=1536, vocab=30522, max_pos=512, pooling="mean",
+         config="BASELINE configs[1] / configs[3] width"),
+    dict(name="bge-large-en-v1.5", layers=24, hidden=1024, heads=16, intermediate=4096, vocab=30522, max_pos=512, pooling="cls",
+         config="BASELINE configs[4] width"),
+]
+
+
+def other_width_section(args, torch, dev, model, rows):
+    """The other model widths of BASELINE.json, driver-timed on a short run (outside `value`): the same fused indexing
+    step (encode + BM25 tf + store) with the named shape, and the dense / batched searches on a corpus of `rows` unit
+    rows of that width."""
+    from voitta_rag_amd import Engine
+    from voitta_rag_amd import encoder as enc
+
+    dim = model["hidden"]
+    gen = torch.Generator(device=dev).manual_seed(77)
+    steps, warm = 3, 1
+    e = Engine(dim, device=dev.index or 0, initial_rows=rows + (steps + warm) * args.batch + 64)
+    state = random_state(torch, gen, dev, model)
+    enc.load_encoder(e, enc.BertDesc(model["layers"], dim, model["heads"], model["intermediate"], vocab=model["vocab"],
+                                     max_pos=model["max_pos"], pooling=model["pooling"], precision=args.precision), state)
+    del state
+    batches = [make_batch(torch, gen, dev, args.batch, i) for i in range(steps + warm)]
+    for b in batches[:warm]:
+        e.index_batch(b[0], b[1], b[2], b[3])
+    e.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[warm:]:
+        e.index_batch(b[0], b[1], b[2], b[3])
+    e.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_flop = e.profile_read(Engine.PROF_GEMM)
+    e.profile(False)
+    del batches
+    for a in range(0, rows, 100_000):
+        n = min(100_000, rows - a)
+        e.upsert(torch.nn.functional.normalize(torch.randn((n, dim), device=dev, generator=gen), dim=1).contiguous())
+    qs = torch.nn.functional.normalize(torch.randn((args.queries + 20, dim), device=dev, generator=gen), dim=1).cpu().numpy()
+    for i in range(20):
+        e.search_dense(qs[i:i + 1], 10)
+    lat = np.empty(200)
+    for i in range(200):
+        t1 = time.perf_counter()
+        e.search_dense(qs[20 + i:21 + i], 10)
+        lat[i] = time.perf_counter() - t1
+    qb = np.ascontiguousarray(qs[20:20 + args.queries])
+    e.search_dense(qb, 10)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        e.search_dense(qb, 10)
+    bdt = (time.perf_counter() - t1) / 3
+    gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    out = {"model": model["name"], "shape": f"L{model['layers']} H{dim} {model['pooling']}", "stands_for": model["config"],
+           "chunks_per_s": round(steps * args.batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "gemm_TFLOPs": round(gemm_tf, 1), "gemm_frac_of_f16_peak": round(gemm_tf / PEAK_F16_MFMA_TFLOPS, 4),
+           "gemm_share_of_step_time": round(gemm_ms * 1e-3 / dt, 4),
+           "corpus_rows": rows, "p50_dense_top10_ms": round(float(np.percentile(lat, 50) * 1e3), 4),
+           "p99_dense_top10_ms": round(float(np.percentile(lat, 99) * 1e3), 4),
+           "qps_dense_batched": round(args.queries / bdt, 1)}
     e.close()
     torch.cuda.empty_cache()
     return out
@@ -413,14 +500,54 @@ def cpu_baseline(args, rng):
     }
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, the same
+    command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment — what torch.distributed.run would
+    set) and wait for them. This parent never touches the GPU (nothing here initialises HIP; a process that has must
+    not be replaced, and is not: the ranks are children). Rank 0 prints the JSON line on the inherited stdout. Any
+    rank failing ends the others and makes the exit code non-zero."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(len(procs)))
+    while pending:
+        for i in list(pending):
+            code = procs[i].poll()
+            if code is None:
+                continue
+            pending.discard(i)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {i} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for j in pending:
+                    procs[j].terminate()
+        time.sleep(0.05)
+    return rc if rc >= 0 else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, or plain "
+                         "python bench.py --gpus N, which starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     if args.share_gpu:
@@ -455,15 +582,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the corpus is sharded by document, every rank indexes its own batches. The only exchange of the indexing
+    # path is the one that keeps the BM25 document frequencies collection-wide: after a batch is stored
+    # its term ids are all-gathered and applied to the other shards' tables — INSIDE the timed step.
+    searcher = None
+    if world > 1:
+        from voitta_rag_amd.sharded import ShardedSearcher
+
+        searcher = ShardedSearcher(engine)
+        searcher.replicate_all()  # the pre-populated shards were filled locally
+
+    def index_step(b):
+        first = engine.index_batch(b[0], b[1], b[2], b[3])
+        if searcher is not None:
+            searcher.rows_added(np.arange(first, first + args.batch, dtype=np.int64))
+
     # ---- indexing: W warm-up steps, then exactly K timed steps ------------------------------------
     for b in batches[: args.warmup]:
-        engine.index_batch(b[0], b[1], b[2], b[3])
+        index_step(b)
     engine.profile(True)
     barrier()
     t0 = time.perf_counter()
     tokens = 0
     for b in batches[args.warmup:]:
-        engine.index_batch(b[0], b[1], b[2], b[3])
+        index_step(b)
         tokens += b[4]
     barrier()
     dt = time.perf_counter() - t0
@@ -486,9 +628,6 @@ def main():
     q_nnz = np.random.default_rng(5).integers(4, 7, size=args.queries + 20)
     ones = np.ones(8, np.float32)
     if world > 1:
-        from voitta_rag_amd.sharded import ShardedSearcher
-
-        searcher = ShardedSearcher(engine)
         search = lambda i: searcher.search_hybrid(qs_host[i], q_terms[i, : q_nnz[i]], ones[: q_nnz[i]], 10, 0.1)  # noqa: E731
     else:
         search = lambda i: engine.search_hybrid(qs_host[i], q_terms[i, : q_nnz[i]], ones[: q_nnz[i]], 10, 0.1)  # noqa: E731
@@ -540,6 +679,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         batch_dt = float(t.item())
     qps_batched = batch_reps * args.queries / batch_dt if batch_dt == batch_dt else None
+    # ---- configs[4]'s query side: all --queries HYBRID top-10 searches in ONE call (dense batch + sparse batch beside
+    # it + fusion on the host threads; N > 1: one all_gather for the whole batch, merge on the engine) ---------------
+    sq_list = [(q_terms[20 + i, : q_nnz[20 + i]], ones[: q_nnz[20 + i]]) for i in range(args.queries)]
+    hyb_call = ((lambda: searcher.search_hybrid_batch(qb, sq_list, 10, 0.1)) if world > 1
+                else (lambda: engine.search_hybrid_batch(qb, sq_list, 10, 0.1)))
+    hyb_batched, hyb_dt, recall_hybrid = None, float("nan"), None
+    try:
+        for _ in range(2):
+            hyb_batched = hyb_call()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(batch_reps):
+            hyb_batched = hyb_call()
+        barrier()
+        hyb_dt = time.perf_counter() - t1
+        # recall@10 against the single-query hybrid path (itself held to the oracle bit for bit by the tests)
+        hits, n_ref = 0, min(100, args.queries)
+        for i in range(n_ref):
+            hits += len(set(np.asarray(search(20 + i)[0]).tolist()) & set(np.asarray(hyb_batched[i][0]).tolist()))
+        recall_hybrid = hits / (10.0 * n_ref)
+    except Exception as exc:
+        print(f"[bench] hybrid batched-query section failed on rank {rank}: {exc!r}", file=sys.stderr, flush=True)
+    if world > 1:
+        t = torch.tensor([hyb_dt], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hyb_dt = float(t.item())
+    qps_hybrid = batch_reps * args.queries / hyb_dt if hyb_dt == hyb_dt else None
     # the same query when it arrives as TEXT: WordPiece ids of a short question (12 tokens) are encoded by
     # the engine first (embed_query's path, embedding.py:76-86), then searched — single GPU only
     enc_lat = full_lat = None
@@ -600,6 +766,16 @@ def main():
         dropin = dropin_section(args, engine, state, np.random.default_rng(17))
     del state
 
+    # ---- the other model widths of BASELINE.json, short runs (outside `value`) ------------------------------------
+    other = None
+    if world == 1 and args.other_rows > 0:
+        other = []
+        for m in OTHER_MODELS:
+            try:
+                other.append(other_width_section(args, torch, dev, m, args.other_rows))
+            except Exception as exc:
+                print(f"[bench] {m['name']} section failed: {exc!r}", file=sys.stderr, flush=True)
+
     if rank == 0:
         gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # ceiling for ALGORITHMIC FLOP/s: the f32 MFMA peak, the dense f16 peak, or a third of it (three passes)
@@ -622,8 +798,10 @@ def main():
                                "accumulate; measured |1-cos| ~5e-8 vs the f64 oracle)",
                       "f16": "f16 (f16 MFMA operands, f32 accumulate; softmax, LayerNorm statistics and pooling in f32; the "
                              "residual stream between layers is stored as f16 (LayerNorm is applied inside the GEMM epilogues from "
-                             "f32 row sums); measured |1-cos| <= 2e-6 vs the f64 oracle on the full 12-layer shape "
-                             "(tests/test_encoder_gpu.py), north_star tolerance 1e-4)"
+                             "f32 row sums); measured |1-cos| = 1.5e-6 vs the f64 oracle on THIS code path at this scale — 2300 "
+                             "sequences / 272k tokens, 12 layers, sampled sequences incl. tile and forward-chunk edges "
+                             "(tests/test_encoder_gpu.py::test_bench_scale_f16_path_against_the_f64_oracle; 4.1e-6 at 24 layers), "
+                             "north_star tolerance 1e-4)"
                       }[args.precision],
             "data": "synthetic (seeded token ids / unit vectors; random-init N(0,0.02) weights of the named shape)",
             "config": {
@@ -648,14 +826,27 @@ def main():
                             f"{batch_reps} calls timed; answers bit-identical to the single-query path (tests/test_search_gpu.py, "
                             "tests/test_fullsize_gpu.py)",
             "ms_per_batched_call": None if qps_batched is None else round(batch_dt / batch_reps * 1e3, 3),
+            "qps_hybrid_batched_1k": None if qps_hybrid is None else round(qps_hybrid, 1),
+            "ms_per_hybrid_batched_call": None if qps_hybrid is None else round(hyb_dt / batch_reps * 1e3, 3),
+            "hybrid_batched_kind": f"{args.queries} hybrid top-10 queries per call (vr_search_hybrid_batch: one batched dense search, one "
+                                   "batched sparse search over the inverted index beside it, min-max fusion of every query on the host "
+                                   "threads; host arrays in and out); answers bit-identical to the single-query path "
+                                   "(tests/test_batch_hybrid_gpu.py, tests/test_fullsize_gpu.py)",
+            "recall_at_10_hybrid_batched_vs_single_query": recall_hybrid,
+            "other_model_widths": other,
             "recall_at_10_batched_vs_torch_matmul": recall_batched,
             "anisotropic_corpus": aniso,
             "dropin_index_chunks_per_s": None if dropin is None else round(dropin[0], 1),
+            "dropin_sync_index_chunks_per_s": None if dropin is None else round(dropin[5], 1),
+            "dropin_sync_kind": None if dropin is None else
+                f"the same per-file sequence in the DEFAULT mode ({dropin[6]} files): embeddings stay token ids until store_chunks, which makes "
+                "ONE fused engine call per file itself and raises where the reference's upsert raises (indexing.py:558-590 contract)",
             "dropin_kind": None if dropin is None else
                 f"{dropin[2]} synthetic documents ({dropin[1]} chunks) from raw text through the reference's per-file sequence "
                 "count_by_file -> delete_by_file -> chunk_text -> embed_texts -> sparse embed_texts -> zip -> store_chunks "
                 "(indexing.py:239,284,513-563) on the drop-in "
-                "classes, one thread, until every row is searchable (write-behind: voitta_rag_amd/deferred.py)",
+                "classes, one thread, until every row is searchable (opt-in write-behind, VOITTA_DEFERRED_INDEXING=1: "
+                "voitta_rag_amd/deferred.py; flush() + failed_file_paths() before the caller commits)",
             "p50_query_from_text_ms": None if dropin is None else round(dropin[3], 4),
             "p99_query_from_text_ms": None if dropin is None else round(dropin[4], 4),
             "query_from_text_kind": "embed_query(text) -> sparse embed_query(text) -> VectorStoreService.search(limit=10, hybrid) "

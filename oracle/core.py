@@ -132,3 +132,21 @@ class SparseOracle:
                                    _p(qi, C.c_int32), _p(qv, C.c_float), len(qi), _p(qdf, C.c_int32),
                                    self.n_points, _p(out, C.c_float))
         return out
+
+    @classmethod
+    def from_csr(cls, off, idx, val, live=None):
+        """The same from CSR arrays whose rows are already sorted by id (full-size tests: no Python loop per row)."""
+        self = cls.__new__(cls)
+        self.off = np.ascontiguousarray(off, np.int64)
+        self.idx = np.ascontiguousarray(idx, np.int32)
+        self.val = np.ascontiguousarray(val, np.float32)
+        n = len(self.off) - 1
+        self.rows = range(n)
+        row_of = np.repeat(np.arange(n), np.diff(self.off))
+        keep = np.ones(len(self.idx), bool) if live is None else np.asarray(live, bool)[row_of]
+        pairs = np.unique(row_of[keep].astype(np.int64) << 31 | self.idx[keep].astype(np.int64))  # a term counts once per row
+        ids, counts = np.unique(pairs & ((1 << 31) - 1), return_counts=True)
+        self.df = dict(zip(ids.tolist(), counts.tolist()))
+        has = np.diff(self.off) >= 0  # every row of a CSR batch carries a sparse vector (possibly empty)
+        self.n_points = int(has.sum() if live is None else (has & np.asarray(live, bool)).sum())
+        return self

@@ -297,3 +297,82 @@ def test_configs3_shard_dense_only_1p25m_x_384(gpu):
         assert np.array_equal(batched[i][0], r1) and np.array_equal(batched[i][1].view(np.uint32), s1.view(np.uint32)), i
     for e in (two, one, *halves):
         e.close()
+
+
+def test_configs4_shard_hybrid_batch_1p25m_x_1024_with_sparse_rows(gpu):
+    """BASELINE configs[4], one rank's share WITH its sparse side: 1.25M x 1024 rows (bge-large width), 24 BM25 terms
+    per row, 1000 hybrid top-10 queries in ONE call (vr_search_hybrid_batch). Every batched answer must equal the
+    single-query vr_search_hybrid bit for bit (rows, f64 fused scores, origin flags) in both fusion modes, and a sample
+    must equal the CPU oracle end to end: oracle dense scores (f32 fma chain) + oracle IDF sparse scores over all
+    1.25M rows -> top-30 each -> oracle/fusion.py (vector_store.py:621-697)."""
+    import torch
+
+    from oracle import fusion as ofus
+    from voitta_rag_amd import Engine
+    from voitta_rag_amd.engine import VR_FUSION_RRF
+
+    n, d, blk, nnz = 1_250_000, 1024, 125_000, 24
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(404)
+    common = torch.nn.functional.normalize(torch.randn(d, device=dev, generator=g), dim=0)
+    e = Engine(d, initial_rows=n)
+    xs, idx_l, val_l = [], [], []
+    for a in range(0, n, blk):
+        x = torch.nn.functional.normalize(torch.randn((blk, d), device=dev, generator=g), dim=1) * (0.5 ** 0.5) + (0.5 ** 0.5) * common[None, :]
+        ids = (torch.rand((blk, nnz), device=dev, generator=g) ** 2 * 50_000).to(torch.int32)
+        ids, _ = torch.sort(ids, dim=1)
+        ids = ids * 32 + torch.arange(nnz, device=dev, dtype=torch.int32)[None, :]          # distinct, ascending
+        off = (torch.arange(blk + 1, device=dev, dtype=torch.int64) * nnz).contiguous()
+        val = (torch.rand((blk * nnz,), device=dev, generator=g) + 0.5).contiguous()
+        e.upsert(x.contiguous(), sparse=(off, ids.reshape(-1).contiguous(), val))
+        xs.append(x.cpu().numpy())
+        idx_l.append(ids.reshape(-1).cpu().numpy())
+        val_l.append(val.cpu().numpy())
+    nq, limit, w = 1000, 10, 0.2
+    rng = np.random.default_rng(9)
+    qs = (torch.nn.functional.normalize(torch.randn((nq, d), device=dev, generator=g), dim=1) * (0.5 ** 0.5) + (0.5 ** 0.5) * common[None, :]).cpu().numpy()
+    sq = []
+    for i in range(nq):
+        m = int(rng.integers(1, 8)) if i % 50 else 0
+        slot = rng.choice(nnz, size=m, replace=False)
+        base = (rng.random(m) ** 2 * 50_000).astype(np.int64)
+        sq.append(((base * 32 + slot).astype(np.int32), rng.uniform(0.5, 1.5, size=m).astype(np.float32)))
+    gone = np.arange(5, n, 997)
+    e.delete_rows(gone)
+    before = e.stats()
+    got = e.search_hybrid_batch(qs, sq, limit, w)
+    assert e.stats()["batched"] - before["batched"] == nq
+    got_rrf = e.search_hybrid_batch(qs, sq, limit, w, fusion=VR_FUSION_RRF)
+    for i in range(nq):
+        r1, s1, f1 = e.search_hybrid(qs[i], sq[i][0], sq[i][1], limit, w)
+        assert got[i][0].tolist() == r1.tolist() and got[i][1].tolist() == s1.tolist() and got[i][2].tolist() == f1.tolist(), i
+        assert np.all(np.diff(got[i][1]) <= 0)
+        if i % 10 == 0:
+            r2, s2, f2 = e.search_hybrid(qs[i], sq[i][0], sq[i][1], limit, w, fusion=VR_FUSION_RRF)
+            assert got_rrf[i][0].tolist() == r2.tolist() and got_rrf[i][1].tolist() == s2.tolist(), i
+    # the sparse legs alone, batched == single
+    sb = e.search_sparse_batch(sq[:200], 30)
+    for i in range(0, 200, 5):
+        r1, s1 = e.search_sparse(sq[i][0], sq[i][1], 30) if len(sq[i][0]) else (np.zeros(0, np.int64), np.zeros(0, np.float32))
+        assert np.array_equal(sb[i][0], r1) and np.array_equal(sb[i][1].view(np.uint32), s1.view(np.uint32)), i
+    # a sample against the oracle, end to end
+    live = np.ones(n, np.uint8)
+    live[gone] = 0
+    x_all = np.concatenate(xs)
+    del xs
+    xh = ocore.cosine_preprocess(x_all)
+    del x_all
+    off_all = np.arange(n + 1, dtype=np.int64) * nnz
+    so = ocore.SparseOracle.from_csr(off_all, np.concatenate(idx_l), np.concatenate(val_l), live.astype(bool))
+    assert so.n_points == n - len(gone)
+    for i in (0, 1, 50, 333, 999):
+        dsc = ocore.dense_scores(ocore.cosine_preprocess(qs[i:i + 1]), xh)[0]
+        dr, ds = ocore.topk(dsc, 3 * limit, live)
+        if len(sq[i][0]):
+            sr, ss = ocore.topk(so.scores(*sq[i]), 3 * limit, live)
+        else:
+            sr, ss = np.zeros(0, np.int64), np.zeros(0, np.float32)
+        want = ofus.hybrid_fuse(list(zip(dr.tolist(), ds.tolist())), list(zip(sr.tolist(), ss.tolist())), limit, w, "json")
+        assert got[i][0].tolist() == [r for r, _, _ in want], i
+        assert got[i][1].tolist() == [s for _, s, _ in want], i
+    e.close()

@@ -111,7 +111,11 @@ class ShardedSearcher:
     def replicate_all(self) -> None:
         """Collective, once, on shards that were filled locally without the exchange above."""
         n_rows, _ = self.local.count()
-        self._exchange_ids(np.arange(n_rows, dtype=np.int64), +1)
+        most = torch.tensor([n_rows], dtype=torch.int64, device=self.comm_device)
+        dist.all_reduce(most, op=dist.ReduceOp.MAX, group=self.group)
+        step = 1 << 17  # rows per exchange: bounds the gathered id buffer (world x step x widest row x 4 B)
+        for a in range(0, int(most.item()), step):  # every rank makes the same number of exchanges
+            self._exchange_ids(np.arange(min(a, n_rows), min(a + step, n_rows), dtype=np.int64), +1)
 
     # ---- the one collective of a query ------------------------------------------------------------
     def _gather_and_merge(self, keys, n_lists: int, k: int):
