@@ -396,6 +396,19 @@ int vr_sparse_row_ids(vr_engine* e, const int64_t* rows, int64_t n, int32_t* out
  * that live on other shards. sign = +1 (stored there) or -1 (deleted there). */
 int vr_df_apply(vr_engine* e, const int32_t* ids, int64_t n_ids, int mem, int64_t n_points, int32_t sign);
 
+/* A question as TEXT, answered in one call: the three calls of the MCP search tool (mcp_server.py:469-485:
+ * embedding_service.embed_query, sparse_service.embed_query, vector_store.search) without the trips through the host
+ * language between them. dense_text: the query as the encoder sees it (with its "query: " prefix for e5 models,
+ * embedding.py:82-83), tokenised by `tokenizer` ([CLS] .. [SEP], truncated to max_len); sparse_text: the raw query for
+ * the BM25 side (Bm25.query_embed: the set of its hashed stems, every value 1.0), or NULL / length 0 for a dense-only
+ * search. Branch selection as VectorStoreService.search (vector_store.py:560-619): hybrid (prefetch 3 x limit, fusion)
+ * when a stem survives, else the dense top-`limit` with its cosine scores widened to f64 (the caller applies the
+ * REST/JSON transport). *out_hybrid says which ran. Needs a loaded encoder with hidden == dim. */
+int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense_text, int64_t dense_len,
+                  const char* sparse_text, int64_t sparse_len, int32_t max_len, int32_t limit, double sparse_weight,
+                  int32_t fusion, const vr_filter* filter,
+                  int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count, int32_t* out_hybrid);
+
 /* Persistence. The reference's index survives a restart in Qdrant's volume
  * (docker-compose.yml:8-9; VectorStoreService._ensure_collection re-attaches, vector_store.py:75-115).
  * vr_save writes everything the device owns — tiled dense corpus, payload columns, tombstones,

@@ -442,3 +442,47 @@ def test_write_behind_stores_exactly_what_the_three_literal_calls_store(native, 
             common = set(g) & set(w)
             assert len(common) >= len(w) - 1 and all(abs(g[key] - w[key]) < 2e-4 for key in common)
     store_registry.reset()
+
+
+def test_a_question_as_text_is_one_engine_call_with_the_same_answer(native):
+    """mcp_server.py:469-485 hands embed_query's and the sparse embed_query's results untouched to search(): while
+    nobody looks at them they are the question's TEXT and the store answers with one engine call (vr_query_text:
+    WordPiece + BM25 tokenise + encode + search). The chunks and scores must be exactly those of the three-call path
+    with materialised vectors — hybrid, the dense-only branch (no stem survives), filters, an e5-style prefix, and
+    search_many must return the same per query."""
+    path, shape, w, vocab = native("e5-mini", "mean")  # "e5" in the name: "query: " / "passage: " prefixes (embedding.py:50,65,82)
+    from voitta_rag_amd import deferred
+    from voitta_rag_amd.embedding import get_embedding_service
+    from voitta_rag_amd.sparse_embedding import get_sparse_embedding_service
+    from voitta_rag_amd.vector_store import ChunkMetadata, get_vector_store
+
+    rng = np.random.default_rng(3)
+    emb, sp, vs = get_embedding_service(), get_sparse_embedding_service(), get_vector_store()
+    texts = _texts(rng, 300)
+    metas = [ChunkMetadata(file_path=f"d{i % 3}/f{i // 10}.md", folder_path=f"d{i % 3}", index_folder=f"d{i % 3}", file_name="f.md",
+                           chunk_index=i, total_chunks=300, start_char=0, end_char=1, indexed_at="t",
+                           source_modified_at=1_700_000_000 + i) for i in range(300)]
+    vs.store_chunks(list(zip(texts, emb.embed_texts(texts), metas)), sparse_vectors=sp.embed_texts(texts))
+    key = lambda c: (c.id, c.score, c.text)  # noqa: E731
+    questions = ["vector database retrieval", "the of and", "hybrid fusion ranking running?", "x", "kernel memory bandwidth wavefront matrix tile"]
+    for qtext in questions:
+        for kw in ({}, {"folder_filter": "d1"}, {"exclude_folders": ["d0"], "date_start": 1_700_000_100}, {"limit": 3, "sparse_weight": 0.5}):
+            q_ref, s_ref = emb.embed_query(qtext), sp.embed_query(qtext)
+            assert isinstance(q_ref, deferred.QueryRef) and not q_ref.materialized and not s_ref.materialized
+            got = vs.search(q_ref, sparse_query=s_ref, **kw)                      # the text path
+            assert not q_ref.materialized and not s_ref.materialized
+            q_arr, s_arr = emb.embed_query(qtext), sp.embed_query(qtext)
+            vec = q_arr.tolist()                                                  # looked at: plain floats, three calls
+            pair = (list(s_arr[0]), list(s_arr[1]))
+            want = vs.search(vec, sparse_query=pair, **kw)
+            assert [key(c) for c in got] == [key(c) for c in want], (qtext, kw)
+            assert len(got) == min(kw.get("limit", 10), len(got)) and (len(got) > 0 or "folder_filter" in kw or "exclude_folders" in kw)
+            # dense only: sparse_query=None
+            assert [key(c) for c in vs.search(emb.embed_query(qtext), **kw)] == [key(c) for c in vs.search(vec, **kw)]
+    # search_many == search per query (hybrid where the query has stems, dense-only where it has none)
+    vecs = np.array([emb.embed_query(q).tolist() for q in questions], np.float32)
+    pairs = [tuple(sp.embed_query(q)) for q in questions]
+    many = vs.search_many(vecs, limit=7, sparse_queries=pairs, sparse_weight=0.3, exclude_folders=["d2"])
+    for i, q in enumerate(questions):
+        one = vs.search(vecs[i].tolist(), limit=7, sparse_query=pairs[i], sparse_weight=0.3, exclude_folders=["d2"])
+        assert [key(c) for c in many[i]] == [key(c) for c in one], q

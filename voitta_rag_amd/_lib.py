@@ -136,6 +136,8 @@ SIGNATURES = {
                                 C.c_int32, C.c_int32, _i64p, _dp, _i32p, _i32p]),
     "vr_sparse_row_ids": (C.c_int, [_vp, _i64p, C.c_int64, _vp, C.c_int64, C.c_int, _i32p, _i64p]),
     "vr_df_apply": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int32]),
+    "vr_query_text": (C.c_int, [_vp, _vp, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_double,
+                                C.c_int32, C.POINTER(VrFilter), _i64p, _dp, _i32p, _i32p, _i32p]),
 }
 
 

@@ -1300,3 +1300,116 @@ int vr_df_apply(vr_engine* e, const int32_t* ids, int64_t n_ids, int mem, int64_
 }
 
 }  // extern "C"
+
+// ---- a question as TEXT, one call (the MCP search tool's three calls — embed_query, sparse embed_query,
+// vector_store.search: mcp_server.py:469-485 — without the trips through Python between them) -----------------------
+
+namespace {
+
+// a few device rows for query embeddings in flight (one per concurrent vr_query_text)
+struct QueryRows {
+  std::mutex mu;
+  std::vector<float*> free_rows;
+  ~QueryRows() {
+    for (float* p : free_rows) (void)hipFree(p);
+  }
+};
+QueryRows g_query_rows[16];  // per device (indexed by ordinal % 16; rows are kMaxDim floats, any engine fits)
+
+float* take_query_row(int device) {
+  QueryRows& q = g_query_rows[device & 15];
+  {
+    std::lock_guard<std::mutex> g(q.mu);
+    if (!q.free_rows.empty()) {
+      float* p = q.free_rows.back();
+      q.free_rows.pop_back();
+      return p;
+    }
+  }
+  float* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(float) * kMaxDim) != hipSuccess) return nullptr;
+  return p;
+}
+
+void give_query_row(int device, float* p) {
+  QueryRows& q = g_query_rows[device & 15];
+  std::lock_guard<std::mutex> g(q.mu);
+  q.free_rows.push_back(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense_text, int64_t dense_len,
+                  const char* sparse_text, int64_t sparse_len, int32_t max_len, int32_t limit, double sparse_weight,
+                  int32_t fusion, const vr_filter* filter, int64_t* out_rows, double* out_scores, int32_t* out_from_dense,
+                  int32_t* out_count, int32_t* out_hybrid) {
+  VR_TRY(check_engine(e));
+  VR_CHECK(tokenizer && dense_text && dense_len >= 0 && out_rows && out_scores && out_count, "bad arguments");
+  VR_CHECK(limit >= 1 && limit * 3 <= kMaxK, "limit = %d not in 1..%d", limit, kMaxK / 3);
+  VR_CHECK(fusion == VR_FUSION_MINMAX || fusion == VR_FUSION_RRF, "unknown fusion %d", fusion);
+  VR_CHECK(max_len >= 2 && max_len <= 4096, "max_len %d", max_len);
+  *out_count = 0;
+  if (out_hybrid) *out_hybrid = 0;
+  // 1. host: WordPiece ids of the (prefixed) query, hashed BM25 stems of the raw query (Bm25.query_embed: the SET of
+  //    them, every value 1.0 — SURVEY.md a7)
+  std::vector<int32_t> wp(static_cast<size_t>(max_len));
+  int64_t wp_off[2] = {0, 0}, needed = 0;
+  {
+    const char* texts[1] = {dense_text};
+    const int64_t lens[1] = {dense_len};
+    VR_TRY(vr_wordpiece_encode(tokenizer, texts, lens, 1, max_len, wp_off, wp.data(), max_len, &needed));
+  }
+  std::vector<int32_t> stems;
+  if (sparse_text && sparse_len > 0) {
+    stems.resize(static_cast<size_t>(sparse_len / 2 + 2));
+    const char* texts[1] = {sparse_text};
+    const int64_t lens[1] = {sparse_len};
+    int64_t off[2] = {0, 0}, need = 0;
+    int rc = vr_bm25_tokenize(texts, lens, 1, off, stems.data(), static_cast<int64_t>(stems.size()), &need);
+    if (rc == -2) {
+      stems.resize(static_cast<size_t>(need));
+      rc = vr_bm25_tokenize(texts, lens, 1, off, stems.data(), static_cast<int64_t>(stems.size()), &need);
+    }
+    VR_TRY(rc);
+    stems.resize(static_cast<size_t>(need));
+    std::sort(stems.begin(), stems.end());
+    stems.erase(std::unique(stems.begin(), stems.end()), stems.end());
+    VR_CHECK(static_cast<int>(stems.size()) <= kMaxQueryTerms, "query with %zu distinct terms", stems.size());
+  }
+  // 2. the embedding, left in device memory (the encoder is shared with the writers: one forward pass at a time)
+  VR_CHECK(encoder_hidden(e) == e->dim, "encoder width %d != store dimension %d", encoder_hidden(e), e->dim);
+  float* q_dev = take_query_row(e->device);
+  VR_CHECK(q_dev != nullptr, "no device memory for the query embedding");
+  struct Giver {
+    int device;
+    float* p;
+    ~Giver() { give_query_row(device, p); }
+  } giver{e->device, q_dev};
+  {
+    const int32_t off32[2] = {0, static_cast<int32_t>(wp_off[1])};
+    std::lock_guard<std::mutex> writer(e->wmu);
+    VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
+  }
+  // 3. the search, on a lane
+  const bool hybrid = !stems.empty();
+  if (out_hybrid) *out_hybrid = hybrid ? 1 : 0;
+  if (hybrid) {
+    std::vector<float> ones(stems.size(), 1.0f);
+    return vr_search_hybrid(e, q_dev, VR_MEM_DEVICE, stems.data(), ones.data(), static_cast<int32_t>(stems.size()), limit,
+                            sparse_weight, fusion, filter, out_rows, out_scores, out_from_dense, out_count);
+  }
+  // no term survived the stop-word filter: the dense-only branch of VectorStoreService.search (vector_store.py:612-617)
+  std::vector<float> sc(static_cast<size_t>(limit));
+  int32_t c = 0;
+  VR_TRY(vr_search_dense(e, q_dev, 1, VR_MEM_DEVICE, limit, filter, out_rows, sc.data(), &c));
+  for (int i = 0; i < c; ++i) {
+    out_scores[i] = static_cast<double>(sc[static_cast<size_t>(i)]);
+    if (out_from_dense) out_from_dense[i] = 1;
+  }
+  *out_count = c;
+  return 0;
+}
+
+}  // extern "C"

@@ -135,6 +135,96 @@ class QueryEmbedding(list):
         self.array = np.ascontiguousarray(array, np.float32)
 
 
+class QueryRef:
+    """What ``embed_query`` returns while nobody has looked at it: the QUESTION ITSELF (its text as the encoder will
+    see it) standing in for the ``list[float]`` of the reference (embedding.py:76-86). Handed untouched to
+    ``VectorStoreService.search`` — all the MCP search tool does with it (mcp_server.py:469-485) — it lets the store
+    answer the question in one engine call (vr_query_text: tokenise, encode, search) instead of three calls with
+    768 Python floats in between; looked at (indexed, iterated, measured, given to NumPy) it computes the embedding
+    and behaves like the list it stands for."""
+
+    def __init__(self, model, text: str):
+        self.model = model    # NativeSentenceEncoder
+        self.text = text
+        self._array: np.ndarray | None = None
+
+    @property
+    def materialized(self) -> bool:
+        return self._array is not None
+
+    @property
+    def array(self) -> np.ndarray:
+        if self._array is None:
+            self._array = np.ascontiguousarray(self.model.encode(self.text, convert_to_numpy=True), np.float32)
+        return self._array
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.array
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self) -> int:
+        return int(self.model.desc.hidden)
+
+    def __getitem__(self, k):
+        v = self.array[k]
+        return float(v) if getattr(v, "ndim", 0) == 0 else v.tolist()
+
+    def __iter__(self):
+        return iter(self.array.tolist())
+
+    def tolist(self) -> list[float]:
+        return self.array.tolist()
+
+    def __eq__(self, other):
+        try:
+            return self.tolist() == list(other)
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self) -> str:
+        return f"<query embedding ({'computed' if self.materialized else 'deferred'}, dim {len(self)})>"
+
+
+class SparseQueryRef:
+    """What the sparse service's ``embed_query`` returns while nobody has looked at it: behaves like the
+    ``(indices, values)`` tuple of the reference (sparse_embedding.py:29-39), computed on first use."""
+
+    def __init__(self, text: str, compute):
+        self.text = text
+        self._compute = compute
+        self._pair: tuple[list[int], list[float]] | None = None
+
+    @property
+    def materialized(self) -> bool:
+        return self._pair is not None
+
+    def _get(self):
+        if self._pair is None:
+            self._pair = self._compute(self.text)
+        return self._pair
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __len__(self) -> int:
+        return 2
+
+    def __bool__(self) -> bool:
+        return True
+
+    def __eq__(self, other):
+        try:
+            return self._get() == tuple(other)
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self) -> str:
+        return f"<bm25 query vector ({'computed' if self.materialized else 'deferred'})>"
+
+
 class SparseRef:
     """Entry ``index`` of a DeferredSparse: behaves like the (indices, values) tuple it stands for."""
 

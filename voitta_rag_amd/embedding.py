@@ -208,7 +208,10 @@ class EmbeddingService:
     def embed_query(self, query: str) -> list[float]:
         if "e5" in self.model_name.lower():  # embedding.py:82-83
             query = f"query: {query}"
-        return _deferred.QueryEmbedding(self.model.encode(query, convert_to_numpy=True))
+        model = self.model
+        if _deferred.enabled() and isinstance(model.tokenizer, WordPieceTokenizer):
+            return _deferred.QueryRef(model, query)  # encoded when looked at — or inside the search call it goes to
+        return _deferred.QueryEmbedding(model.encode(query, convert_to_numpy=True))
 
 
 _embedding_service: EmbeddingService | None = None

@@ -421,6 +421,22 @@ class Engine:
         n = int(cnt[0])
         return rows[:n].copy(), scores[:n].copy(), fd[:n].copy()
 
+    def query_text(self, tokenizer_handle, dense_text: str, sparse_text: str | None, max_len: int, limit: int,
+                   sparse_weight: float = 0.1, fusion: int = VR_FUSION_MINMAX, flt: SearchFilter | None = None):
+        """A question as text in ONE engine call (vr_query_text): WordPiece + BM25 tokenise + encode + hybrid (or, when
+        no stem survives, dense) search. -> (rows int64[c], scores f64[c], from_dense int32[c], hybrid: bool)."""
+        d = dense_text.encode("utf-8", "replace")
+        sp = sparse_text.encode("utf-8", "surrogatepass") if sparse_text else None
+        rows, scores, fd = np.empty(limit, np.int64), np.empty(limit, np.float64), np.empty(limit, np.int32)
+        cnt, hyb = C.c_int32(), C.c_int32()
+        fp, keep = self._filter(flt)
+        check(self._lib.vr_query_text(self._h, tokenizer_handle, d, len(d), sp, len(sp) if sp else 0, int(max_len), limit,
+                                      float(sparse_weight), fusion, fp, _ptr(rows, C.c_int64), _ptr(scores, C.c_double),
+                                      _ptr(fd, C.c_int32), C.byref(cnt), C.byref(hyb)))
+        del keep
+        n = int(cnt.value)
+        return rows[:n], scores[:n], fd[:n], bool(hyb.value)
+
     # ---- many queries per call (BASELINE configs[4]: 1k batched hybrid queries) -----------------------------------
     @staticmethod
     def _sparse_csr(sparse_queries, nq: int):

@@ -42,6 +42,8 @@ class SparseEmbeddingService:
         return [(idx.tolist(), val.tolist()) for idx, val in self.model.bm25_tf(offsets, stems)]
 
     def embed_query(self, query: str) -> tuple[list[int], list[float]]:
+        if _deferred.enabled():
+            return _deferred.SparseQueryRef(query, _query_vector)  # computed when looked at, or inside the search call
         return _query_vector(query)
 
     @property

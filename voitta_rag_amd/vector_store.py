@@ -800,8 +800,26 @@ class VectorStoreService:
             return []  # Qdrant answers limit=0 with no points (a caller-supplied MCP argument, mcp_server.py:376,474)
         col = self._col
         self._drain(col, surface_errors=False)
-        kept = getattr(query_embedding, "array", None) if isinstance(query_embedding, _deferred.QueryEmbedding) else None
-        if (kept is not None and len(query_embedding) == kept.size == self.dimension
+        # a question that is still TEXT (embed_query / sparse embed_query results nobody looked at): one engine call
+        # does the tokenising, the encode and the search (vr_query_text) — mcp_server.py:469-485 without the Python in between
+        if (isinstance(query_embedding, _deferred.QueryRef) and not query_embedding.materialized
+                and query_embedding.model.engine is self._engine and int(query_embedding.model.desc.hidden) == self.dimension
+                and (sparse_query is None or (isinstance(sparse_query, _deferred.SparseQueryRef) and not sparse_query.materialized))):
+            model = query_embedding.model
+            sparse_text = sparse_query.text if (sparse_query is not None and self._has_sparse) else None
+
+            def run_text(search_filter):
+                rows, scores, _fd, was_hybrid = self._engine.query_text(model.tokenizer._h, query_embedding.text, sparse_text,
+                                                                        model.max_seq_length, limit, sparse_weight, flt=search_filter)
+                return rows, ([float(s) for s in scores] if was_hybrid else [_json_float(np.float32(s)) for s in scores])
+
+            rows, scores = self._search_consistent(col, run_text, folder_filter, include_folders, exclude_folders,
+                                                   exclude_index_folders, date_start, date_end, date_field)
+            return [self._chunk_from(pid, payload, s) for (pid, payload), s in zip(rows, scores) if payload is not None]
+        kept = getattr(query_embedding, "array", None) if isinstance(query_embedding, (_deferred.QueryEmbedding, _deferred.QueryRef)) else None
+        if isinstance(query_embedding, _deferred.QueryRef):
+            q = kept.reshape(self.dimension)
+        elif (kept is not None and len(query_embedding) == kept.size == self.dimension
                 and query_embedding[0] == float(kept[0]) and query_embedding[-1] == float(kept[-1])):  # (not edited since)
             q = kept.reshape(self.dimension)  # (embed_query's own array; the list was not needed)
         else:
