@@ -80,6 +80,34 @@ def test_sparse_batch_against_the_oracle_and_the_single_search(small):
                     assert np.array_equal(got[i][0], r1) and np.array_equal(got[i][1].view(np.uint32), s1.view(np.uint32))
 
 
+def test_sparse_batch_pruning_keeps_the_exact_answer(small, monkeypatch):
+    """One block per query walks ALL segments (VR_SPARSE_BATCH_BLOCKS=1): after the first segment its lists are full and
+    the others are scanned with dynamic pruning (csrc/invert.hip: only the essential terms' postings, candidates scored
+    from the forward index). Rows, scores and order must still be the oracle's, bit for bit — common terms (every row
+    has them: pure non-essential ballast), rare terms, a filter, and k from 1 to 64."""
+    from voitta_rag_amd import SearchFilter
+
+    e, rng, x, sp, folder, live, vocab = small
+    df = sp.df
+    common = sorted(df, key=lambda t: -df[t])[:5]
+    rare = sorted(df, key=lambda t: df[t])[:200]
+    qs = []
+    for i in range(80):
+        terms = list(rng.choice(common, size=int(rng.integers(0, 3)), replace=False)) + list(rng.choice(rare, size=int(rng.integers(0, 4)), replace=False))
+        if not terms:
+            terms = [common[0]]
+        qs.append((np.array(terms, np.int32), rng.uniform(0.5, 1.5, size=len(terms)).astype(np.float32)))
+    for blocks in ("1", "2"):
+        monkeypatch.setenv("VR_SPARSE_BATCH_BLOCKS", blocks)
+        for flt, mask in ((None, live.astype(bool)), (SearchFilter(exclude_folders=[3]), live.astype(bool) & (folder != 3))):
+            for k in (1, 10, 30, 64):
+                got = e.search_sparse_batch(qs, k, flt)
+                for i, (qi, qv) in enumerate(qs):
+                    wr, ws = ocore.topk(sp.scores(qi, qv), k, mask.astype(np.uint8))
+                    assert np.array_equal(got[i][0], wr), (blocks, k, i)
+                    assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), (blocks, k, i)
+
+
 def test_sparse_batch_with_given_weights(small):
     e, rng, x, sp, folder, live, vocab = small
     qs = [(np.sort(rng.choice(vocab, size=4, replace=False)).astype(np.int32) * 7919 + 13, rng.uniform(0.1, 3.0, size=4).astype(np.float32))

@@ -756,6 +756,45 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 
 }  // extern "C"
 
+// Both legs of ONE hybrid query on the latency path (`e` is a search lane, n_rows > 0): the k dense keys end up in the
+// pinned result area at kPinDenseKeys, the k sparse keys (when *have_sparse) at kPinSparseKeys; returns with the stream
+// drained. The two legs share nothing but the mask: the (small, latency-bound) sparse leg is forked onto the auxiliary
+// stream and runs under the dense scan. The k > kFusedMaxK sparse path borrows the dense leg's selection buffers and
+// stays on the main stream.
+static int hybrid_one_query(vr_engine* e, const float* q, int mem, const int32_t* q_idx, const float* q_val, int nnz, int k,
+                            bool weights_given, const uint8_t* mask, bool* have_sparse_out) {
+  const float* q_dev = stage_query(e, q, 1, mem);
+  bool two_stage = false;
+  const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
+  *have_sparse_out = have_sparse;
+  const bool fork = have_sparse && k <= kFusedMaxK;
+  if (have_sparse) VR_CHECK(q_idx && q_val, "null sparse query");
+  if (fork) VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask, before the dense leg
+  VR_TRY(search_dense_block(e, q_dev, 1, k, mask, true, &two_stage));
+  if (fork) {
+    // queued after the dense leg (whose scan is already running by now), executed beside it
+    VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+    hipStream_t main_stream = e->stream;
+    e->stream = e->aux_stream;
+    const int rc = search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given);
+    e->stream = main_stream;
+    if (rc != 0) return rc;
+    VR_HIP(hipEventRecord(e->ev_join, e->aux_stream));
+    VR_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  } else if (have_sparse) {
+    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given));
+  }
+  VR_HIP(hipStreamSynchronize(e->stream));
+  e->stat_two_stage += two_stage;
+  if (two_stage) e->stat_last_candidates.store(*pin_host<int32_t>(e, kPinCandCount));
+  if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
+    ++e->stat_fallback;
+    VR_TRY(search_dense_block(e, q_dev, 1, k, mask, false));  // candidate overflow: one-stage exact scan
+    VR_HIP(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
 // Dense search of nq queries; the nq x k ranking keys ((order-preserving f32 score bits << 32) | ~row, descending,
 // 0 = none) go to keys_host (host array) and/or keys_dev (device array). `e` is a search lane (SearchLane).
 static int search_dense_keys_locked(vr_engine* e, const float* q, int nq, int mem, int k, const vr_filter* filter,
@@ -908,43 +947,12 @@ int vr_search_hybrid(vr_engine* e, const float* q, int mem, const int32_t* q_idx
   const int k = limit * 3;  // prefetch_limit, vector_store.py:636
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
-  const uint64_t* dense_keys = pin_host<uint64_t>(e, kPinDenseKeys);
-  const uint64_t* sparse_keys = pin_host<uint64_t>(e, kPinSparseKeys);
-  const float* q_dev = stage_query(e, q, 1, mem);
-  bool two_stage = false;
-  const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
-  // The two legs share nothing but the mask: the (small, latency-bound) sparse leg is forked onto
-  // the auxiliary stream and runs under the dense scan. The k > kFusedMaxK sparse path borrows the
-  // dense leg's selection buffers and stays on the main stream.
-  const bool fork = have_sparse && k <= kFusedMaxK;
-  if (have_sparse) VR_CHECK(q_idx && q_val, "null sparse query");
-  if (fork) VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask, before the dense leg
-  VR_TRY(search_dense_block(e, q_dev, 1, k, mask, true, &two_stage));
-  if (fork) {
-    // queued after the dense leg (whose scan is already running by now), executed beside it
-    VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
-    hipStream_t main_stream = e->stream;
-    e->stream = e->aux_stream;
-    const int rc = search_sparse_block(e, q_idx, q_val, nnz, k, mask, false);
-    e->stream = main_stream;
-    if (rc != 0) return rc;
-    VR_HIP(hipEventRecord(e->ev_join, e->aux_stream));
-    VR_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-  } else if (have_sparse) {
-    VR_TRY(search_sparse_block(e, q_idx, q_val, nnz, k, mask, false));
-  }
-  VR_HIP(hipStreamSynchronize(e->stream));
-  e->stat_two_stage += two_stage;
-  if (two_stage) e->stat_last_candidates.store(*pin_host<int32_t>(e, kPinCandCount));
-  if (two_stage && *pin_host<int32_t>(e, kPinCandCount) > kMaxCandidates) {
-    ++e->stat_fallback;
-    VR_TRY(search_dense_block(e, q_dev, 1, k, mask, false));  // candidate overflow: one-stage exact scan
-    VR_HIP(hipStreamSynchronize(e->stream));
-  }
+  bool have_sparse = false;
+  VR_TRY(hybrid_one_query(e, q, mem, q_idx, q_val, nnz, k, false, mask, &have_sparse));
   int64_t d_rows[kMaxK], s_rows[kMaxK];
   float d_scores[kMaxK], s_scores[kMaxK];
-  int nd = static_cast<int>(decode_keys(dense_keys, k, d_rows, d_scores));
-  int ns = have_sparse ? static_cast<int>(decode_keys(sparse_keys, k, s_rows, s_scores)) : 0;
+  int nd = static_cast<int>(decode_keys(pin_host<uint64_t>(e, kPinDenseKeys), k, d_rows, d_scores));
+  int ns = have_sparse ? static_cast<int>(decode_keys(pin_host<uint64_t>(e, kPinSparseKeys), k, s_rows, s_scores)) : 0;
   if (fusion == VR_FUSION_MINMAX)
     return fuse_minmax(d_rows, d_scores, nd, s_rows, s_scores, ns, limit, sparse_weight, 1, out_rows,
                        out_scores, out_from_dense, out_count);
@@ -1092,6 +1100,16 @@ int hybrid_keys_locked(vr_engine* e, const float* q, int nq, int mem, const int6
   }
   const uint8_t* mask = nullptr;
   VR_TRY(filter_build_mask(e, filter, &mask));
+  if (nq == 1) {  // one query: the latency path (query in the pinned area / kernel arguments, both legs side by side)
+    const int nnz = sq_off ? static_cast<int>(sq_off[1] - sq_off[0]) : 0;
+    bool sparse_ran = false;
+    VR_TRY(hybrid_one_query(e, q, mem, nnz ? sq_idx + sq_off[0] : nullptr, nnz ? sq_val + sq_off[0] : nullptr, nnz, k,
+                            weights_given, mask, &sparse_ran));
+    memcpy(dense_host, pin_host<uint64_t>(e, kPinDenseKeys), bytes);
+    if (sparse_ran) memcpy(sparse_host, pin_host<uint64_t>(e, kPinSparseKeys), bytes);
+    else memset(sparse_host, 0, bytes);
+    return 0;
+  }
   const bool have_sparse = sq_off != nullptr && sq_off[nq] > sq_off[0] && e->n_slices_dev > 0;
   SparseBatch b;
   if (have_sparse) {

@@ -46,6 +46,7 @@
 namespace vr {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kBQ = 128;          // queries per block column
 constexpr int kBStage = 64 * 1024;  // bytes per stage: 16 tiles x 2 kb8 KiB of rows + 8 qfrags x {a,b} x 2 kb8 KiB
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict
     float v = row[i];
     if (len > 0.0f) v = __fdiv_rn(v, len);
     row[i] = v;
-    qhat[static_cast<int64_t>(qi) * dim + i] = v;
+    // q^ as the B operand of the exact re-score's v_mfma_f32_16x16x4_f32 chain: [kb][g] float4 whose component c is
+    // element 16 kb + 4 c + g (what a lane of k-group g supplies for the c-th MFMA of k-block kb)
+    qhat[static_cast<int64_t>(qi) * dim + (i / 16) * 16 + (i % 4) * 4 + (i % 16) / 4] = v;
     mx = fmaxf(mx, fabsf(v));
     n2 += v * v;
   }
@@ -435,47 +438,65 @@ __global__ void batch_threshold_kernel(const uint64_t* __restrict__ keys, int nq
 
 // ---- exact re-score of the (query, candidate row) pairs --------------------------------------------------
 
-// One lane per pair: the k-ordered f32 fma chain from +0.0 over the stored (tiled) row and q^ — bit for bit what
-// the v_mfma_f32_16x16x4_f32 chain of dense.hip returns. keys[q][slot] (0 beyond the query's count).
+// A wave per (query, 16 of its candidate rows): the rows — from sixteen different tiles — are gathered straight into the
+// A operand of dense.hip's v_mfma_f32_16x16x4_f32 chain (lane g * 16 + r fetches the 16 bytes that hold elements
+// 16 kb + 4 c + g, c = 0..3, of candidate r: the tiled corpus stores exactly that float4), the query's image (written
+// by batch_prep_kernel in B-operand order, the same value in all sixteen columns) is the B operand, and the chain runs in
+// k order from +0.0 — bit for bit the one-stage scan's score (and the fmaf chain this kernel replaced, which walked a row
+// per LANE: 16 useful bytes of every 128 fetched, 768 dependent steps). keys[q][slot] (0 beyond the query's count).
 __global__ __launch_bounds__(256) void batch_rescore_kernel(const float4* __restrict__ corpus,
-                                                            const float* __restrict__ qhat,
+                                                            const float4* __restrict__ qimg,
                                                             const int32_t* __restrict__ cand,
                                                             const int32_t* __restrict__ cand_cnt, int nq, int dim,
                                                             int kblocks, uint64_t* __restrict__ keys) {
-  const int64_t pair = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int q = static_cast<int>(pair / kBatchCand), slot = static_cast<int>(pair % kBatchCand);
-  if (q >= nq) return;
-  uint64_t key = 0ull;
-  if (slot < min(cand_cnt[q], kBatchCand)) {
-    const int64_t row = cand[pair];
-    const int64_t tile = row / kTileRows;
-    const int r = static_cast<int>(row % kTileRows);
-    const float4* x = corpus + tile * kblocks * 64 + r;  // block kb: float4 at lane g * 16 + r holds k = 16 kb + 4 c + g
-    const float4* qv = reinterpret_cast<const float4*>(qhat + static_cast<int64_t>(q) * dim);
-    float acc = 0.0f;
-    for (int kb = 0; kb < kblocks; ++kb) {
-      const float4 x0 = x[kb * 64], x1 = x[kb * 64 + 16], x2 = x[kb * 64 + 32], x3 = x[kb * 64 + 48];  // g = 0..3
-      const float4 q0 = qv[kb * 4], q1 = qv[kb * 4 + 1], q2 = qv[kb * 4 + 2], q3 = qv[kb * 4 + 3];       // c = 0..3
-      acc = fmaf(x0.x, q0.x, acc);  // k = 16 kb + 0 .. 3: c = 0, g = 0..3
-      acc = fmaf(x1.x, q0.y, acc);
-      acc = fmaf(x2.x, q0.z, acc);
-      acc = fmaf(x3.x, q0.w, acc);
-      acc = fmaf(x0.y, q1.x, acc);  // c = 1
-      acc = fmaf(x1.y, q1.y, acc);
-      acc = fmaf(x2.y, q1.z, acc);
-      acc = fmaf(x3.y, q1.w, acc);
-      acc = fmaf(x0.z, q2.x, acc);  // c = 2
-      acc = fmaf(x1.z, q2.y, acc);
-      acc = fmaf(x2.z, q2.z, acc);
-      acc = fmaf(x3.z, q2.w, acc);
-      acc = fmaf(x0.w, q3.x, acc);  // c = 3
-      acc = fmaf(x1.w, q3.y, acc);
-      acc = fmaf(x2.w, q3.z, acc);
-      acc = fmaf(x3.w, q3.w, acc);
-    }
-    key = topk_make_key(acc, row);
+  const int lane = threadIdx.x & 63;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);  // (query, 16 slots)
+  constexpr int kGroups = kBatchCand / 16;
+  const int q = static_cast<int>(group / kGroups), slot0 = static_cast<int>(group % kGroups) * 16;
+  if (q >= nq) return;  // wave-uniform
+  uint64_t* out = keys + static_cast<int64_t>(q) * kBatchCand + slot0;
+  const int cnt = min(cand_cnt[q], kBatchCand);
+  if (slot0 >= cnt) {  // wave-uniform: nothing in this group
+    if (lane < 16) out[lane] = 0ull;
+    return;
   }
-  keys[pair] = key;
+  const int r = lane & 15, g = lane >> 4;
+  const bool valid = slot0 + r < cnt;
+  const int64_t row = cand[static_cast<int64_t>(q) * kBatchCand + (valid ? slot0 + r : slot0)];  // (a real row either way)
+  const float4* xp = corpus + (row / kTileRows) * kblocks * 64 + g * 16 + (row % kTileRows);
+  const float4* qp = qimg + static_cast<int64_t>(q) * kblocks * 4 + g;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  int kb = 0;
+  for (; kb + 8 <= kblocks; kb += 8) {  // eight gathers in flight per lane
+    float4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = xp[(kb + u) * 64];
+      b[u] = qp[(kb + u) * 4];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+  for (; kb < kblocks; ++kb) {
+    const float4 a = xp[kb * 64], b = qp[kb * 4];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  // C/D map: lane holds rows 4 g + reg of column (lane & 15); every column carries the same query
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = 4 * g + reg;
+    const int64_t row_i = __shfl(static_cast<long long>(row), i);  // lane i gathered candidate i
+    const bool valid_i = slot0 + i < cnt;
+    if (r == 0) out[i] = valid_i ? topk_make_key(acc[reg], row_i) : 0ull;
+  }
 }
 
 // one block per query: the k best of its <= kBatchCand exact keys (k rounds of block-wide extract-max),
@@ -601,8 +622,9 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   prof_end(e);
   uint64_t* keys = e->bq_keys.p;
   uint64_t* out = keys + static_cast<int64_t>(nq) * kBatchCand;
-  hipLaunchKernelGGL(batch_rescore_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(nq) * kBatchCand / 256)), dim3(256),
-                     0, s, reinterpret_cast<const float4*>(e->corpus.p), e->bq_hat.p, e->bq_cand.p, e->bq_cnt.p, nq, dim,
+  hipLaunchKernelGGL(batch_rescore_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(nq) * (kBatchCand / 16) / 4)), dim3(256),
+                     0, s, reinterpret_cast<const float4*>(e->corpus.p), reinterpret_cast<const float4*>(e->bq_hat.p), e->bq_cand.p,
+                     e->bq_cnt.p, nq, dim,
                      e->kblocks, keys);
   hipLaunchKernelGGL(batch_final_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, s, keys, e->bq_cnt.p,
                      two_pass ? static_cast<const int32_t*>(nullptr) : e->bq_pairs.p + pair_cap, k, out, e->bq_cnt.p + nq);

@@ -3010,6 +3010,10 @@ int encoder_load(vr_engine* e, const vr_bert_desc* d, const void* const* t, int 
 
 static int ensure_workspace(vr_engine* e, Encoder* enc, int64_t tokens) {
   if (tokens <= enc->ws_tokens) return 0;
+  // Headroom: batches of the same chunk count differ by a per cent or two in tokens, and a workspace that fits the
+  // largest batch SO FAR exactly is freed and reallocated (gigabytes, with a device synchronisation) every time a
+  // slightly longer one arrives — 200 ms per step at the bge-large shape. A sixteenth more, in whole 4096-token units.
+  if (tokens > 4096) tokens = (tokens + tokens / 16 + 4095) / 4096 * 4096;
   VR_HIP(hipStreamSynchronize(e->stream));
   invalidate_graphs(enc);
   for (float** p : {&enc->x, &enc->qkv, &enc->ctx, &enc->tmp, &enc->ffn, &enc->xs, &enc->lnstat, &enc->lnpart}) {

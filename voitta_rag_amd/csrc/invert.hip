@@ -240,6 +240,31 @@ __global__ void inv_segments_kernel(const uint64_t* __restrict__ keys, int64_t n
   out[j] = s;
 }
 
+// The largest |weight| among a segment's postings, kept in its descriptor (InvSeg::pad, as float bits): the query
+// kernels bound what a term can add to any row of the segment by |q_t idf_t| * vmax (dynamic pruning, below).
+// One block per segment.
+__global__ __launch_bounds__(256) void inv_vmax_kernel(InvSeg* __restrict__ segs, const float* __restrict__ vals) {
+  __shared__ float red[4];
+  InvSeg* seg = segs + blockIdx.x;
+  const float* vp = vals + seg->off;
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < seg->count; i += 256) {
+    const float a = fabsf(vp[i]);
+    m = (a > m || a != a) ? a : m;  // a NaN sticks: such a segment is never pruned
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(m, off);
+    m = (o > m || o != o) ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
+    seg->pad = __float_as_int(m);
+  }
+}
+
 // counter[1] += postings equal to their left neighbour (a row that lists a term twice)
 __global__ void inv_count_dups_kernel(const uint64_t* __restrict__ keys, int64_t n, unsigned long long* counter) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -336,6 +361,8 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
   hipLaunchKernelGGL(inv_segments_kernel, dim3(static_cast<unsigned>((n_sub + 255) / 256)), dim3(256), 0, e->stream,
                      keys, nnz, e->inv_used, first_row, n_rows, seg_rows, static_cast<int>(n_sub),
                      e->inv_seg.p + e->n_inv_seg);
+  hipLaunchKernelGGL(inv_vmax_kernel, dim3(static_cast<unsigned>(n_sub)), dim3(256), 0, e->stream, e->inv_seg.p + e->n_inv_seg,
+                     e->inv_val.p);
   VR_HIP(hipGetLastError());
   e->inv_used += nnz;
   e->n_inv_seg += n_sub;
@@ -411,22 +438,84 @@ struct InvQuery {
 
 // LDS of one block of the inverted scan (single-query and batched kernels share it and the body below)
 struct InvShared {
-  float score[kInvSegRows];
+  float score[kInvSegRows];   // (pruned segments: the candidate rows' numbers, as int32, in the same bytes)
   uint8_t hit[kInvSegRows];
   int32_t t_id[kInvMaxTerms];
   float t_w[kInvMaxTerms];
   int32_t t_lo[kInvMaxTerms];
+  int32_t t_ord[kInvMaxTerms];  // term indices by ascending |weight|
+  float t_pre[kInvMaxTerms];    // t_pre[j] = |w| of terms t_ord[0..j] summed (rounded up)
   uint64_t lists[kInvWaves * kListLen];
   uint64_t tmax[kInvWaves * 64];
   uint64_t blk_thr;
+  int32_t n_cand;
 };
+
+// the forward (SELL-64) side of the index, which the pruned path of the inverted scan reads row by row
+struct InvForward {
+  const int32_t* row_slice;
+  const SliceDesc* slices;
+  const int32_t* sidx;
+  const float* sval;
+};
+
+__device__ __forceinline__ float inv_key_score(uint64_t key) {
+  const uint32_t hi = static_cast<uint32_t>(key >> 32);
+  return __uint_as_float((hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi);
+}
+
+// The exact score of one row for the query in sh.t_id / sh.t_w (ascending ids): the row's own entries are walked in
+// ascending id order and every shared term adds fl(fl(w * v)) to the sum from +0.0 — the forward scan's arithmetic
+// (sparse.hip) and the inverted accumulation's, hence their bits. *hit: the row shares a term with the query.
+__device__ __forceinline__ float inv_row_score(const InvShared& sh, const InvForward& fw, int64_t row, int nnz, bool* hit) {
+  float acc = 0.0f;
+  *hit = false;
+  const int32_t s = fw.row_slice[row];
+  if (s < 0) return acc;
+  const SliceDesc d = fw.slices[s];
+  const int lane = static_cast<int>(row - d.row_base);
+  const int32_t last = sh.t_id[nnz - 1];
+  int qp = 0;
+  for (int c = 0; c < d.width / 4; ++c) {
+    const int64_t at = d.off + static_cast<int64_t>(c) * 256 + lane * 4;
+    const int4 ids = *reinterpret_cast<const int4*>(fw.sidx + at);
+    const int32_t id4[4] = {ids.x, ids.y, ids.z, ids.w};
+    bool done = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t id = id4[u];
+      if (id < 0 || id > last) {  // padding (real ids are a prefix of the row) or beyond the query's last term
+        done = true;
+        break;
+      }
+      while (qp < nnz && sh.t_id[qp] < id) ++qp;
+      if (qp < nnz && sh.t_id[qp] == id) {
+        acc = __fadd_rn(acc, __fmul_rn(sh.t_w[qp], fw.sval[at + u]));
+        *hit = true;
+      }
+    }
+    if (done) break;
+  }
+  return acc;
+}
 
 // The block's share of the segments (s0, s0 + s_step, ...) for ONE query whose terms (ascending ids) and weights
 // already sit in sh.t_id / sh.t_w; leaves the block's k best keys in sh.lists[0 .. kListLen) (wave 0's list).
+//
+// Dynamic pruning (exact; the MaxScore idea). A block walks several segments for one query and its lists fill up: once
+// a wave's list holds k keys, the k-th of them is a LOWER bound theta of the final k-th best score. A term t can add
+// at most |w_t| vmax to a row of a segment (vmax: the segment's largest |weight|, in its descriptor), so with the terms
+// ordered by |w_t| the first j of them are NON-ESSENTIAL when (|w_(1)| + .. + |w_(j)|) vmax < theta: a row that shares
+// only such terms with the query cannot reach the top k. Their postings — the long lists of the common terms, which
+// every query of a Zipfian vocabulary carries — are then not read at all: only the ESSENTIAL terms' postings are walked
+// (to mark rows), and every marked row is scored exactly from its own forward (SELL) entries, in ascending id order —
+// the same sum, the same bits. With theta unknown (the first segments of a block, or a list that never fills) and for
+// negative thresholds the full accumulation below runs. The sums are rounded up and compared strictly, so a row that
+// ties with theta is never pruned.
 __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* __restrict__ segs, int n_seg, int s0,
                                                   int s_step, const uint64_t* __restrict__ keys,
                                                   const float* __restrict__ vals, int nnz,
-                                                  const uint8_t* __restrict__ mask, int k) {
+                                                  const uint8_t* __restrict__ mask, int k, const InvForward fw) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   uint64_t* list = sh.lists + wave * kListLen;
@@ -435,11 +524,90 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
   const int32_t* t_id = sh.t_id;
   const float* t_w = sh.t_w;
   int32_t* t_lo = sh.t_lo;
+  if (threadIdx.x == 0) {  // terms by ascending |weight| (<= 32 of them: insertion sort), and the running sums
+    for (int i = 0; i < nnz; ++i) {
+      const float a = fabsf(t_w[i]);
+      int j = i;
+      while (j > 0 && fabsf(t_w[sh.t_ord[j - 1]]) > a) {
+        sh.t_ord[j] = sh.t_ord[j - 1];
+        --j;
+      }
+      sh.t_ord[j] = i;
+    }
+    float run = 0.0f;
+    for (int j = 0; j < nnz; ++j) {
+      run = (run + fabsf(t_w[sh.t_ord[j]])) * 1.000001f;
+      sh.t_pre[j] = run;
+    }
+  }
+  __syncthreads();
   for (int s = s0; s < n_seg; s += s_step) {
     const InvSeg seg = segs[s];
     if (seg.count == 0) continue;  // block-uniform
     const uint64_t* kp = keys + seg.off;
     const float* vp = vals + seg.off;
+    // theta: the best k-th key any wave of the block holds (block-uniform: the lists are only written between barriers)
+    uint64_t theta_key = 0ull;
+#pragma unroll
+    for (int w = 0; w < kInvWaves; ++w) {
+      const uint64_t kth = sh.lists[w * kListLen + (k - 1)];
+      theta_key = kth > theta_key ? kth : theta_key;
+    }
+    int n_ne = 0;  // non-essential terms: t_ord[0 .. n_ne)
+    if (theta_key != 0ull) {
+      const float theta = inv_key_score(theta_key);
+      const float vmax = __int_as_float(seg.pad);
+      while (n_ne < nnz && sh.t_pre[n_ne] * vmax * 1.00001f < theta) ++n_ne;  // (false for NaN / inf / theta <= 0)
+    }
+    if (n_ne > 0) {
+      // ---- pruned: mark the rows the essential terms name, score those rows exactly from the forward index ----
+      for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) hit[r] = 0;
+      if (threadIdx.x == 0) sh.n_cand = 0;
+      const int n_es = nnz - n_ne;
+      for (int j = wave; j < n_es; j += kInvWaves) {
+        const int i = sh.t_ord[n_ne + j];
+        const int lb = inv_wave_lower_bound(kp, seg.count, t_id[i], lane);
+        if (lane == 0) t_lo[i] = lb;
+      }
+      __syncthreads();
+      for (int j = 0; j < n_es; ++j) {
+        const int i = sh.t_ord[n_ne + j];
+        const int32_t t = t_id[i];
+        for (int p = t_lo[i] + static_cast<int>(threadIdx.x);; p += kInvWaves * 64) {
+          bool in_run = false;
+          if (p < seg.count) {
+            const uint64_t k2 = kp[p];
+            in_run = inv_term(k2) == t;
+            if (in_run) hit[static_cast<int>(k2 & (kInvSegRows - 1))] = 1;
+          }
+          if (!__all(in_run)) break;  // a wave's chunks only move away from the term's run
+        }
+      }
+      __syncthreads();
+      int32_t* cand = reinterpret_cast<int32_t*>(score);
+#pragma unroll
+      for (int j = 0; j < kInvSegRows / (kInvWaves * 64); ++j) {
+        const int r = static_cast<int>(threadIdx.x) + j * kInvWaves * 64;
+        if (r < seg.nrows && hit[r]) cand[atomicAdd(&sh.n_cand, 1)] = r;
+      }
+      __syncthreads();
+      const int n_cand = sh.n_cand;
+      for (int c0 = 0; c0 < n_cand; c0 += kInvWaves * 64) {  // block-uniform trip count (wave_offer is wave-collective)
+        const int c = c0 + static_cast<int>(threadIdx.x);
+        uint64_t key = 0ull;
+        if (c < n_cand) {
+          const int64_t row = static_cast<int64_t>(seg.row_base) + cand[c];
+          if (mask[row]) {
+            bool shares = false;
+            const float sc = inv_row_score(sh, fw, row, nnz, &shares);
+            if (shares) key = topk_make_key(sc, row);
+          }
+        }
+        wave_offer(list, k, key, 0, key != 0ull, lane);
+      }
+      __syncthreads();  // the next segment reads the lists (theta) and clears the marks
+      continue;
+    }
     for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) {
       score[r] = 0.0f;
       hit[r] = 0;
@@ -507,7 +675,7 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
         }
       }
     }
-    if (threadIdx.x == 0) sh.blk_thr = 0ull;
+    if (threadIdx.x == 0) sh.blk_thr = theta_key;  // (a full list's k-th key already is such a bound: no ranking then)
     __syncthreads();
     // Selection. Thousands of rows may have been hit and a list insert is serial work for its wave, so first a
     // bound: a thread takes rows tid, tid + 256, ...; the k-th largest of the 256 per-thread maxima has k keys at or
@@ -524,7 +692,7 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
     }
     sh.tmax[threadIdx.x] = best;
     __syncthreads();
-    if (best) {
+    if (best && theta_key == 0ull) {
       int rank = 0;
       for (int j = 0; j < kInvWaves * 64; ++j) rank += sh.tmax[j] > best;
       if (rank == k - 1) sh.blk_thr = best;
@@ -546,7 +714,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const InvQuery query, int nnz, int weights_given,
     const int32_t* __restrict__ df_keys, const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
-    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand, const InvForward fw) {
   __shared__ InvShared sh;
   sh.lists[threadIdx.x] = 0ull;  // blockDim.x == kInvWaves * kListLen
   if (static_cast<int>(threadIdx.x) < nnz) {
@@ -555,7 +723,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     sh.t_w[threadIdx.x] = sparse_query_weight(query.val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
   }
   __syncthreads();
-  inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k);
+  inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);
   if (threadIdx.x < kListLen) cand[static_cast<int64_t>(blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
 
@@ -577,7 +745,7 @@ __global__ void sparse_batch_weights_kernel(const int32_t* __restrict__ ids, con
 __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
-    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand) {
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand, const InvForward fw) {
   __shared__ InvShared sh;
   const int qy = blockIdx.y;
   const int t0 = q_off[qy];
@@ -588,7 +756,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     sh.t_w[threadIdx.x] = q_w[t0 + threadIdx.x];
   }
   __syncthreads();
-  if (nnz > 0) inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k);  // block-uniform
+  if (nnz > 0) inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);  // block-uniform
   if (threadIdx.x < kListLen)
     cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
@@ -609,7 +777,7 @@ int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
   hipLaunchKernelGGL(sparse_inv_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kInvWaves * 64), 0, e->stream,
                      e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, query, nnz,
                      weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap, n_points, mask_dev, k,
-                     e->sp_cand.p);
+                     e->sp_cand.p, InvForward{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p});
   prof_end(e);
   VR_HIP(hipGetLastError());
   return topk_merge_lists(e, e->sp_cand.p, blocks, 1, k, out_keys_dev);
@@ -627,13 +795,18 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
                        n_points, q_w_dev);
   // a block walks its share of the segments for one query; enough blocks to fill the chip several times over, few
   // enough lists per query for one merge block (and a candidate array of nq x gx x 512 B)
-  int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (16384 + nq - 1) / nq)));
+  // (few blocks per query: a block that walks many segments scans the first of them in full and — once its lists hold
+  // k keys — only the essential terms' postings of the others, see inv_scan_segments. VR_SPARSE_BATCH_BLOCKS sets the
+  // blocks per query for tests.)
+  int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (4096 + nq - 1) / nq)));
+  if (const char* v = std::getenv("VR_SPARSE_BATCH_BLOCKS")) gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max(1, atoi(v))));
   gx = std::min(gx, kScanBlocks);
   VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * gx * kListLen, 0, e->stream));
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
   hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
                      0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
-                     q_ids_dev, q_w_dev, mask_dev, k, e->sp_cand.p);
+                     q_ids_dev, q_w_dev, mask_dev, k, e->sp_cand.p,
+                     InvForward{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p});
   prof_end(e);
   VR_HIP(hipGetLastError());
   return topk_merge_lists(e, e->sp_cand.p, gx, nq, k, out_keys_dev);
