@@ -93,3 +93,73 @@ def test_rrf_random_lists():
     for _ in range(300):
         nd, ns = rng.integers(0, 91, size=2)
         _run_rrf(rng.permutation(200)[:nd].tolist(), rng.permutation(200)[:ns].tolist(), int(rng.integers(1, 31)))
+
+
+def test_json_transport_fast_path_equals_python_float_of_the_shortest_decimal():
+    """fusion.cpp parses the shortest round-tripping decimal of an f32 itself when it is <= 15 digits times a power of
+    ten within 10^+-22 (one correctly rounded operation) and leaves the rest to strtod. Triples of NEIGHBOURING f32
+    values across 40 decades: the normalised middle value (pb - pa) / (pc - pa) moves if any of the three parses is off
+    by one ulp of f64."""
+    from voitta_rag_amd.engine import fuse_minmax
+
+    rng = np.random.default_rng(1)
+    for _ in range(3000):
+        a = np.float32(10.0 ** rng.uniform(-30, 30) * rng.choice([-1, 1]))
+        b = a
+        for _ in range(int(rng.integers(1, 40))):
+            b = np.nextafter(b, np.float32(np.inf), dtype=np.float32)
+        c = b
+        for _ in range(int(rng.integers(1, 40))):
+            c = np.nextafter(c, np.float32(np.inf), dtype=np.float32)
+        pa, pb, pc = (float(str(v)) for v in (a, b, c))
+        rows, scores, _ = fuse_minmax([0, 1, 2], [a, b, c], [], [], 3, 0.0, True)
+        assert dict(zip(rows.tolist(), scores.tolist()))[1] == (pb - pa) / (pc - pa), (a, b, c)
+
+
+def test_fuse_batch_equals_fuse_per_query_and_survives_repeated_and_concurrent_calls():
+    """vr_fuse_batch runs on the library's parked host threads (csrc/host_parallel.h): many calls in a row, and from
+    several Python threads at once (the loop that finds the pool busy runs inline), return what vr_fuse_minmax /
+    vr_fuse_rrf return per query."""
+    import threading
+
+    from voitta_rag_amd.engine import VR_FUSION_RRF, fuse_batch, fuse_minmax, fuse_rrf
+
+    rng = np.random.default_rng(4)
+    nq, k, limit = 300, 30, 10
+    d_ids = np.stack([rng.choice(5000, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    s_ids = np.stack([rng.choice(5000, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    d_sc = -np.sort(-rng.random((nq, k)).astype(np.float32), axis=1)
+    s_sc = -np.sort(-(rng.random((nq, k)) * 20).astype(np.float32), axis=1)
+    d_cnt = rng.integers(0, k + 1, size=nq).astype(np.int32)
+    s_cnt = rng.integers(0, k + 1, size=nq).astype(np.int32)
+    want = [fuse_minmax(d_ids[i, :d_cnt[i]], d_sc[i, :d_cnt[i]], s_ids[i, :s_cnt[i]], s_sc[i, :s_cnt[i]], limit, 0.3, True) for i in range(nq)]
+    want_rrf = [fuse_rrf(d_ids[i, :d_cnt[i]], s_ids[i, :s_cnt[i]], limit) for i in range(nq)]
+
+    def check():
+        rows, scores, fd, cnt = fuse_batch(d_ids, d_sc, d_cnt, s_ids, s_sc, s_cnt, limit, 0.3)
+        for i in range(nq):
+            c = int(cnt[i])
+            assert rows[i, :c].tolist() == want[i][0].tolist() and scores[i, :c].tolist() == want[i][1].tolist()
+            assert fd[i, :c].tolist() == want[i][2].tolist()
+        rows, scores, fd, cnt = fuse_batch(d_ids, d_sc, d_cnt, s_ids, s_sc, s_cnt, limit, 0.3, VR_FUSION_RRF)
+        for i in range(0, nq, 7):
+            c = int(cnt[i])
+            assert rows[i, :c].tolist() == want_rrf[i][0].tolist() and scores[i, :c].tolist() == want_rrf[i][1].tolist()
+
+    for _ in range(5):
+        check()
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(3):
+                check()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors

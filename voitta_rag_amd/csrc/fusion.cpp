@@ -29,9 +29,40 @@ namespace vr {
 
 static double to_python_float(float s, int json_scores) {
   if (!json_scores) return static_cast<double>(s);
+  // shortest round-tripping decimal of the f32 (what the server prints), read back as the nearest f64 (what Python's
+  // float() returns). The decimal has at most 9 significant digits, so for the exponents scores have it is ONE exactly
+  // representable integer times or divided by ONE exactly representable power of ten — a single correctly rounded
+  // operation, i.e. strtod's own fast path; anything else goes to strtod.
   char buf[64];
-  auto r = std::to_chars(buf, buf + sizeof(buf) - 1, s);
+  auto r = std::to_chars(buf, buf + sizeof(buf) - 1, s, std::chars_format::scientific);
   *r.ptr = '\0';
+  const char* p = buf;
+  const bool neg = *p == '-';
+  if (neg) ++p;
+  uint64_t digits = 0;
+  int nd = 0, point_at = -1;
+  bool plain = true;
+  for (; *p && *p != 'e'; ++p) {
+    if (*p == '.') {
+      point_at = nd;
+    } else if (*p >= '0' && *p <= '9') {
+      digits = digits * 10 + static_cast<uint64_t>(*p - '0');
+      ++nd;
+    } else {
+      plain = false;  // inf / nan
+      break;
+    }
+  }
+  if (plain && *p == 'e' && nd >= 1 && nd <= 15) {
+    const int e10 = atoi(p + 1) - (point_at < 0 ? 0 : nd - point_at);  // value = digits * 10^e10
+    static const double kPow10[] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    if (e10 >= -22 && e10 <= 22) {
+      const double d = static_cast<double>(digits);
+      const double v = e10 < 0 ? d / kPow10[-e10] : d * kPow10[e10];
+      return neg ? -v : v;
+    }
+  }
   return std::strtod(buf, nullptr);
 }
 
