@@ -1045,7 +1045,7 @@ int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool 
   VR_TRY(e->sq_off.grow(nq + 1, 0, e->stream));
   VR_TRY(e->sq_ids.grow(std::max<int64_t>(nt, 1), 0, e->stream));
   VR_TRY(e->sq_val.grow(std::max<int64_t>(nt, 1), 0, e->stream));
-  VR_TRY(e->sq_w.grow(std::max<int64_t>(nt, 1), 0, e->stream));
+  VR_TRY(e->sq_w.grow(std::max<int64_t>(2 * nt, 1), 0, e->stream));  // weights, then the terms' document-frequency shares
   VR_TRY(e->sq_keys.grow(static_cast<int64_t>(nq) * k, 0, e->stream));
   if (nt == 0 || e->n_rows == 0 || e->n_slices_dev == 0) {
     VR_HIP(hipMemsetAsync(e->sq_keys.p, 0, sizeof(uint64_t) * static_cast<size_t>(nq) * k, e->stream));

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const float4* __rest
   const int r = lane & 15, g = lane >> 4;
   const bool valid = slot0 + r < cnt;
   const int64_t row = cand[static_cast<int64_t>(q) * kBatchCand + (valid ? slot0 + r : slot0)];  // (a real row either way)
-  const float4* xp = corpus + (row / kTileRows) * kblocks * 64 + g * 16 + (row % kTileRows);
+  const float4* xp = corpus + (row / kTileRows) * kblocks * 64 + tile_pos(g, static_cast<int>(row % kTileRows));
   const float4* qp = qimg + static_cast<int64_t>(q) * kblocks * 4 + g;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
   int kb = 0;

@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(const float* __restri
   const int ro = static_cast<int>(r_old % kTileRows), rn = static_cast<int>(r_new % kTileRows);
   for (int k = lane; k < dim; k += 64) {
     const int kb = k / kTileK, kk = k % kTileK;
-    const int64_t in_tile = (static_cast<int64_t>(kb) * 64 + (kk % 4) * 16) * 4 + kk / 4;
-    dst[tn * kblocks * 256 + in_tile + rn * 4] = src[to * kblocks * 256 + in_tile + ro * 4];  // 256 floats per 1-KiB block
+    const int64_t in_blk = static_cast<int64_t>(kb) * 256 + kk / 4;  // 256 floats per 1-KiB block
+    dst[tn * kblocks * 256 + in_blk + tile_pos(kk % 4, rn) * 4] = src[to * kblocks * 256 + in_blk + tile_pos(kk % 4, ro) * 4];
   }
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void tile_write_kernel(const float* __restrict
     v.z = __fdiv_rn(v.z, len);
     v.w = __fdiv_rn(v.w, len);
   }
-  reinterpret_cast<float4*>(corpus)[(tile * kblocks + kb) * 64 + lane] = v;
+  reinterpret_cast<float4*>(corpus)[(tile * kblocks + kb) * 64 + tile_pos(g, r)] = v;
 }
 
 int dense_store_rows(vr_engine* e, const float* x_dev, int64_t n, int64_t first_row) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float4* __restr
   const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * 4;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wave; tile < n_tiles;
        tile += wave_stride) {
-    const f32x4 acc = scan_tile(corpus + tile * kblocks * 64 + lane, q_lds, kblocks, lane);
+    const f32x4 acc = scan_tile(corpus + tile * kblocks * 64 + tile_pos(lane >> 4, lane & 15), q_lds, kblocks, lane);
     // C/D map of the 16x16 MFMA: column (query) = lane & 15, rows = 4*(lane >> 4) + reg.
     const int q = lane & 15;
     if (q < nq) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kScanWaves * 64) void dense_scan_topk_kernel(
   const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kScanWaves;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kScanWaves + wave; tile < n_tiles;
        tile += wave_stride) {
-    const f32x4 acc = scan_tile(corpus + tile * kblocks * 64 + lane, q_lds, kblocks, lane);
+    const f32x4 acc = scan_tile(corpus + tile * kblocks * 64 + tile_pos(lane >> 4, lane & 15), q_lds, kblocks, lane);
     const int64_t row0 = tile * kTileRows + (lane >> 4) * 4;
     const uchar4 m = *reinterpret_cast<const uchar4*>(mask + row0);
     const uint64_t k0 = m.x ? topk_make_key(acc[0], row0) : 0ull;
@@ -322,7 +322,7 @@ __global__ void read_rows_kernel(const float* __restrict__ corpus, const int64_t
   for (int k = threadIdx.x; k < dim; k += blockDim.x) {
     int kb = k / kTileK, kk = k % kTileK;
     int c = kk / 4, g = kk % 4;
-    out[i * dim + k] = corpus[((tile * kblocks + kb) * 64 + g * 16 + r) * 4 + c];
+    out[i * dim + k] = corpus[((tile * kblocks + kb) * 64 + tile_pos(g, r)) * 4 + c];
   }
 }
 

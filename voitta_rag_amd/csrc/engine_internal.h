@@ -100,6 +100,13 @@ constexpr int kInvSegRows = 1 << kInvRowBits;
 constexpr int kInvSubShift = 43;
 constexpr int kInvMaxTerms = 32;   // queries with more distinct terms take the forward (SELL) scan
 
+// Position, in float4 units, of the four floats that lane group g (= k % 4) of row r owns inside a 1-KiB block (16 rows
+// x 16 k) of the tiled f32 corpus. The 64 bytes a ROW owns of a block are contiguous (r * 4 + g): the exact re-score of
+// single rows (batch.hip) then fetches half a cache line per block, not four sixteen-byte pieces of four lines — and
+// a wave that reads the whole block, one float4 per lane, still covers the same contiguous KiB. (Until round 3 the
+// position was g * 16 + r: file layout version 2 -> 3.)
+constexpr inline int tile_pos(int g, int r) { return r * 4 + g; }
+
 constexpr int kTileRows = 16;      // corpus rows per MFMA tile (v_mfma_f32_16x16x4_f32 M)
 constexpr int kTileK = 16;         // k elements per 1-KiB tile block
 constexpr int kTopkSeg = 4096;     // keys per block in the first select level
@@ -165,7 +172,7 @@ struct vr_engine {
   int64_t n_live = 0;
   int64_t cap_rows = 0;  // multiple of 64
 
-  // dense corpus, MFMA-tiled: [row/16][k/16][lane = (k%4)*16 + row%16][c = (k%16)/4]
+  // dense corpus, MFMA-tiled: [row/16][k/16][tile_pos(k%4, row%16)][c = (k%16)/4]
   vr::DevArray<float> corpus;
   // f16 shadow of the corpus for the two-stage exact search (prefilter.hip), present when dim % 32 == 0
   // and not disabled: [row/16][k/32][lane = (k%32)/8*16 + row%16][8 halfs], plus the exact
@@ -379,7 +386,7 @@ bool inv_usable(const vr_engine* e, int nnz);
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
                   float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev);
 // many queries in one launch: CSR in device memory (ascending distinct ids, <= kInvMaxTerms per query; raw values in
-// q_val_dev, weights written to q_w_dev); nq x k keys to out_keys_dev
+// q_val_dev; q_w_dev: room for 2 x n_terms floats — the weights, then the terms' df shares); nq x k keys to out_keys_dev
 int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q_ids_dev, const float* q_val_dev,
                         float* q_w_dev, int nq, int n_terms, bool weights_given, float n_points, const uint8_t* mask_dev,
                         int k, uint64_t* out_keys_dev);

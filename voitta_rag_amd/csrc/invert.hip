@@ -443,6 +443,7 @@ struct InvShared {
   int32_t t_id[kInvMaxTerms];
   float t_w[kInvMaxTerms];
   int32_t t_lo[kInvMaxTerms];
+  float t_frac[kInvMaxTerms];   // share of the rows that carry the term (df / N; 1 = unknown)
   int32_t t_ord[kInvMaxTerms];  // term indices by ascending |weight|
   float t_pre[kInvMaxTerms];    // t_pre[j] = |w| of terms t_ord[0..j] summed (rounded up)
   uint64_t lists[kInvWaves * kListLen];
@@ -558,6 +559,17 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
       const float theta = inv_key_score(theta_key);
       const float vmax = __int_as_float(seg.pad);
       while (n_ne < nnz && sh.t_pre[n_ne] * vmax * 1.00001f < theta) ++n_ne;  // (false for NaN / inf / theta <= 0)
+    }
+    if (n_ne > 0) {
+      // worth it? Scoring a marked row from the forward index costs about as much as adding thirty postings, so the
+      // pruned path must have few rows to mark: judged by the terms' document frequencies (every thread, same result)
+      float ess = 0.0f, all = 0.0f;
+      for (int j = 0; j < nnz; ++j) {
+        const float f = sh.t_frac[sh.t_ord[j]];
+        all += f;
+        if (j >= n_ne) ess += f;
+      }
+      if (!(ess * 32.0f < all)) n_ne = 0;
     }
     if (n_ne > 0) {
       // ---- pruned: mark the rows the essential terms name, score those rows exactly from the forward index ----
@@ -721,6 +733,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     const int32_t id = query.id[threadIdx.x];
     sh.t_id[threadIdx.x] = id;
     sh.t_w[threadIdx.x] = sparse_query_weight(query.val[threadIdx.x], id, weights_given, df_keys, df_cnt, df_cap, n_points);
+    sh.t_frac[threadIdx.x] = sparse_term_fraction(id, weights_given, df_keys, df_cnt, df_cap, n_points);
   }
   __syncthreads();
   inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);
@@ -735,9 +748,11 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
 __global__ void sparse_batch_weights_kernel(const int32_t* __restrict__ ids, const float* __restrict__ vals, int n,
                                             int weights_given, const int32_t* __restrict__ df_keys,
                                             const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points,
-                                            float* __restrict__ out) {
+                                            float* __restrict__ out, float* __restrict__ frac) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = sparse_query_weight(vals[i], ids[i], weights_given, df_keys, df_cnt, df_cap, n_points);
+  if (i >= n) return;
+  out[i] = sparse_query_weight(vals[i], ids[i], weights_given, df_keys, df_cnt, df_cap, n_points);
+  frac[i] = sparse_term_fraction(ids[i], weights_given, df_keys, df_cnt, df_cap, n_points);
 }
 
 // q_off[nq + 1]: the terms of query y are ids / w [q_off[y], q_off[y + 1]) — ascending, distinct, at most
@@ -745,7 +760,8 @@ __global__ void sparse_batch_weights_kernel(const int32_t* __restrict__ ids, con
 __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
-    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand, const InvForward fw) {
+    const float* __restrict__ q_frac, const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand,
+    const InvForward fw) {
   __shared__ InvShared sh;
   const int qy = blockIdx.y;
   const int t0 = q_off[qy];
@@ -754,6 +770,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
   if (static_cast<int>(threadIdx.x) < nnz) {
     sh.t_id[threadIdx.x] = q_ids[t0 + threadIdx.x];
     sh.t_w[threadIdx.x] = q_w[t0 + threadIdx.x];
+    sh.t_frac[threadIdx.x] = q_frac[t0 + threadIdx.x];
   }
   __syncthreads();
   if (nnz > 0) inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);  // block-uniform
@@ -792,20 +809,20 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
   if (n_terms > 0)
     hipLaunchKernelGGL(sparse_batch_weights_kernel, dim3(static_cast<unsigned>((n_terms + 255) / 256)), dim3(256), 0,
                        e->stream, q_ids_dev, q_val_dev, n_terms, weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap,
-                       n_points, q_w_dev);
+                       n_points, q_w_dev, q_w_dev + n_terms);
   // a block walks its share of the segments for one query; enough blocks to fill the chip several times over, few
   // enough lists per query for one merge block (and a candidate array of nq x gx x 512 B)
   // (few blocks per query: a block that walks many segments scans the first of them in full and — once its lists hold
   // k keys — only the essential terms' postings of the others, see inv_scan_segments. VR_SPARSE_BATCH_BLOCKS sets the
   // blocks per query for tests.)
-  int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (4096 + nq - 1) / nq)));
+  int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (16384 + nq - 1) / nq)));
   if (const char* v = std::getenv("VR_SPARSE_BATCH_BLOCKS")) gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max(1, atoi(v))));
   gx = std::min(gx, kScanBlocks);
   VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * gx * kListLen, 0, e->stream));
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
   hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
                      0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
-                     q_ids_dev, q_w_dev, mask_dev, k, e->sp_cand.p,
+                     q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p,
                      InvForward{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p});
   prof_end(e);
   VR_HIP(hipGetLastError());

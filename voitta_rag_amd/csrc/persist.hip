@@ -21,7 +21,7 @@ namespace vr {
 
 namespace {
 
-constexpr uint32_t kFileVersion = 1;
+constexpr uint32_t kFileVersion = 3;  // 3: tile_pos() layout of the f32 corpus blocks (engine_internal.h)
 constexpr size_t kChunk = size_t(32) << 20;  // staging buffer (pinned)
 
 struct FileHeader {

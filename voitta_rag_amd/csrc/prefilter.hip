@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restric
   float e2 = 0.0f;
   for (int k = lane; k < dim; k += 64) {
     const int kb = k / kTileK, kk = k % kTileK;
-    const float x = corpus[((tile * kblocks + kb) * 64 + (kk % 4) * 16 + r) * 4 + kk / 4];
+    const float x = corpus[((tile * kblocks + kb) * 64 + tile_pos(kk % 4, r)) * 4 + kk / 4];
     const float xc = fminf(fmaxf(x, -65504.0f), 65504.0f);
     const half_t h = static_cast<half_t>(xc);
     const float d = x - static_cast<float>(h);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void shadow_rows8_kernel(const float* __restri
   const int kb8n = dim / kK8;
   auto at = [&](int k) {  // the residual x - centre (the row itself while there is no centre yet)
     const int kb = k / kTileK, kk = k % kTileK;
-    const float x = corpus[((tile * kblocks + kb) * 64 + (kk % 4) * 16 + r) * 4 + kk / 4];
+    const float x = corpus[((tile * kblocks + kb) * 64 + tile_pos(kk % 4, r)) * 4 + kk / 4];
     return centre ? x - centre[k] : x;
   };
   float mx = 0.0f;
@@ -157,12 +157,12 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
   const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * 64;
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   for (int p = threadIdx.x; p < kblocks * 256; p += 256) {
-    const int kb = p >> 8, lane = (p >> 2) & 63, c = p & 3;
-    const int r = lane & 15;
+    const int kb = p >> 8, pos = (p >> 2) & 63, c = p & 3;  // pos = tile_pos(g, r) = r * 4 + g
+    const int r = pos >> 2;
     float acc = 0.0f;
     for (int64_t t = tile0; t < min(tile0 + 64, n_tiles); ++t)
       if (t * kTileRows + r < n_rows) acc += corpus[(t * kblocks + kb) * 256 + p - (kb << 8)];
-    atomicAdd(sum + kb * kTileK + (lane >> 4) + 4 * c, acc);  // k = kTileK kb + (k % 4 = lane / 16) + 4 (k % 16 / 4 = c)
+    atomicAdd(sum + kb * kTileK + (pos & 3) + 4 * c, acc);  // k = kTileK kb + (k % 4 = g) + 4 (k % 16 / 4 = c)
   }
 }
 
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(const float4* 
       if (wave == 0) {
 #pragma unroll 4
         for (int kb = 0; kb < nkb; ++kb) {
-          const float4 a = stage[kb * 64 + lane];
+          const float4 a = stage[kb * 64 + tile_pos(lane >> 4, lane & 15)];
           const float4 b = stage[(chunk + kb) * 64 + lane];
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);

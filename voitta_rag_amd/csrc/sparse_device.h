@@ -23,6 +23,15 @@ __device__ __forceinline__ int32_t df_get(const int32_t* keys, const int32_t* cn
   return 0;
 }
 
+// Share of the sparse points that carry term `id` (df_t / N; 1 when the statistics are not the engine's own): what the
+// inverted scan's pruning uses to tell a long posting list from a short one before it has looked at either.
+__device__ __forceinline__ float sparse_term_fraction(int32_t id, int weights_given, const int32_t* __restrict__ df_keys,
+                                                      const int32_t* __restrict__ df_cnt, int64_t df_cap, float n_points) {
+  if (weights_given || df_cap == 0 || !(n_points > 0.0f)) return 1.0f;
+  const float f = static_cast<float>(df_get(df_keys, df_cnt, df_cap, id)) / n_points;
+  return f < 1.0f ? f : 1.0f;
+}
+
 // Weight of one query term: q_t as given, or q_t * idf_t with idf_t = ln(1 + (N - df_t + 0.5)/(df_t + 0.5)) —
 // the argument formed in f32, ln taken in f64 and rounded once (SURVEY.md a13 [EXT]). Both scans call this, so
 // their weights are the same bits.
