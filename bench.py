@@ -657,7 +657,9 @@ def main():
     # ---- batched queries: all --queries dense top-10 searches in ONE call -----------
     # host arrays in, host arrays out (queries up, rows + scores down are inside the timed region)
     qb = np.ascontiguousarray(qs_host[20:20 + args.queries])
-    batch_call = (lambda: searcher.search_dense_batch(qb, 10)) if world > 1 else (lambda: engine.search_dense(qb, 10))
+    # (N = 1: the result arrays as the C-ABI fills them — rows / scores [queries, 10] and counts; cutting them into a Python
+    # list of 2000 small arrays is a tenth of the call)
+    batch_call = (lambda: searcher.search_dense_batch(qb, 10)) if world > 1 else (lambda: engine.search_dense(qb, 10, raw=True))
     batch_reps = 5
     try:
         for _ in range(2):
@@ -683,7 +685,7 @@ def main():
     # it + fusion on the host threads; N > 1: one all_gather for the whole batch, merge on the engine) ---------------
     sq_list = [(q_terms[20 + i, : q_nnz[20 + i]], ones[: q_nnz[20 + i]]) for i in range(args.queries)]
     hyb_call = ((lambda: searcher.search_hybrid_batch(qb, sq_list, 10, 0.1)) if world > 1
-                else (lambda: engine.search_hybrid_batch(qb, sq_list, 10, 0.1)))
+                else (lambda: engine.search_hybrid_batch(qb, sq_list, 10, 0.1, raw=True)))
     hyb_batched, hyb_dt, recall_hybrid = None, float("nan"), None
     try:
         for _ in range(2):
@@ -697,7 +699,8 @@ def main():
         # recall@10 against the single-query hybrid path (itself held to the oracle bit for bit by the tests)
         hits, n_ref = 0, min(100, args.queries)
         for i in range(n_ref):
-            hits += len(set(np.asarray(search(20 + i)[0]).tolist()) & set(np.asarray(hyb_batched[i][0]).tolist()))
+            got_rows = hyb_batched[i][0] if world > 1 else hyb_batched[0][i, : hyb_batched[3][i]]
+            hits += len(set(np.asarray(search(20 + i)[0]).tolist()) & set(np.asarray(got_rows).tolist()))
         recall_hybrid = hits / (10.0 * n_ref)
     except Exception as exc:
         print(f"[bench] hybrid batched-query section failed on rank {rank}: {exc!r}", file=sys.stderr, flush=True)
@@ -740,7 +743,7 @@ def main():
             hits = 0
             for i in range(nq):
                 ref = torch.topk(xs @ qs[20 + i], 10).indices.cpu().numpy()
-                got = np.asarray(batched[i][0])
+                got = np.asarray(batched[0][i, : batched[2][i]])
                 got = got[got < args.corpus]
                 hits += len(set(ref.tolist()) & set(got.tolist()))
             recall_batched = hits / (10.0 * nq)

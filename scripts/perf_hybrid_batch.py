@@ -40,8 +40,12 @@ def timed(name, fn, n=reps):
     return out
 
 
-timed("dense batch k=10", lambda: e.search_dense(qs, 10))
-timed("dense batch k=30", lambda: e.search_dense(qs, 30))
+for kk in (10, 30):
+    s0 = e.stats()
+    timed(f"dense batch k={kk} (raw arrays)", lambda: e.search_dense(qs, kk, raw=True))
+    s1 = e.stats()
+    print(f"  candidates re-scored per query: {(s1['batch_candidates'] - s0['batch_candidates']) / max(s1['batched'] - s0['batched'], 1):.1f}, "
+          f"fallbacks {s1['batch_fallback'] - s0['batch_fallback']}")
 e.profile(True)
 sp = timed("sparse batch k=30", lambda: e.search_sparse_batch(sq, 30))
 ms, n, _ = e.profile_read(Engine.PROF_SPARSE_SCAN)
@@ -55,5 +59,4 @@ timed("fuse_batch", lambda: fuse_batch(g[:, 0], s[:, 0], c[:, 0], g[:, 1], s[:, 
 timed("100 single sparse k=30", lambda: [e.search_sparse(sq[i][0], sq[i][1], 30) for i in range(100)], 2)
 timed("100 single hybrid limit=10", lambda: [e.search_hybrid(qs[i], sq[i][0], sq[i][1], 10, 0.1) for i in range(100)], 2)
 timed("1 hybrid keys (nq=1) x100", lambda: [e.search_hybrid_keys(qs[i:i + 1], sq[i:i + 1], 30) for i in range(100)], 2)
-print("hits per query (rows sharing a term), first 5:", [int((np.isin(np.arange(1), 0)).sum()) for _ in range(0)])
 e.close()

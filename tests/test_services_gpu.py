@@ -236,8 +236,8 @@ def test_collection_survives_a_restart(native, tmp_path, monkeypatch):
              for i in range(len(texts))]
     ids = vs.store_chunks(list(zip(texts, emb.embed_texts(texts), metas)), sparse_vectors=sp.embed_texts(texts))
     assert vs.delete_by_file("docs/f1.md") == 20
-    q = emb.embed_query(texts[0])
-    sq = sp.embed_query(texts[0])
+    q = emb.embed_query(texts[0]).tolist()   # plain data: it must outlive the engine it was computed on (the "restart" below)
+    sq = tuple(sp.embed_query(texts[0]))
     want = [(c.id, c.score, c.text, c.metadata) for c in vs.search(q, limit=10, sparse_query=sq, sparse_weight=0.2)]
     want_dense = [(c.id, c.score) for c in vs.search(q, limit=5, folder_filter="docs")]
     info = vs.get_collection_info()

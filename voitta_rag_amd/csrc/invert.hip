@@ -500,31 +500,10 @@ __device__ __forceinline__ float inv_row_score(const InvShared& sh, const InvFor
   return acc;
 }
 
-// The block's share of the segments (s0, s0 + s_step, ...) for ONE query whose terms (ascending ids) and weights
-// already sit in sh.t_id / sh.t_w; leaves the block's k best keys in sh.lists[0 .. kListLen) (wave 0's list).
-//
-// Dynamic pruning (exact; the MaxScore idea). A block walks several segments for one query and its lists fill up: once
-// a wave's list holds k keys, the k-th of them is a LOWER bound theta of the final k-th best score. A term t can add
-// at most |w_t| vmax to a row of a segment (vmax: the segment's largest |weight|, in its descriptor), so with the terms
-// ordered by |w_t| the first j of them are NON-ESSENTIAL when (|w_(1)| + .. + |w_(j)|) vmax < theta: a row that shares
-// only such terms with the query cannot reach the top k. Their postings — the long lists of the common terms, which
-// every query of a Zipfian vocabulary carries — are then not read at all: only the ESSENTIAL terms' postings are walked
-// (to mark rows), and every marked row is scored exactly from its own forward (SELL) entries, in ascending id order —
-// the same sum, the same bits. With theta unknown (the first segments of a block, or a list that never fills) and for
-// negative thresholds the full accumulation below runs. The sums are rounded up and compared strictly, so a row that
-// ties with theta is never pruned.
-__device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* __restrict__ segs, int n_seg, int s0,
-                                                  int s_step, const uint64_t* __restrict__ keys,
-                                                  const float* __restrict__ vals, int nnz,
-                                                  const uint8_t* __restrict__ mask, int k, const InvForward fw) {
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  uint64_t* list = sh.lists + wave * kListLen;
-  float* score = sh.score;
-  uint8_t* hit = sh.hit;
-  const int32_t* t_id = sh.t_id;
+// sh.t_ord: the query's terms by ascending |weight| (ties: by index), sh.t_pre: the running sums of those weights
+// (rounded up). Thread 0 sorts (<= 32 terms: insertion sort); every thread of the block calls this.
+__device__ __forceinline__ void inv_order_terms(InvShared& sh, int nnz) {
   const float* t_w = sh.t_w;
-  int32_t* t_lo = sh.t_lo;
   if (threadIdx.x == 0) {  // terms by ascending |weight| (<= 32 of them: insertion sort), and the running sums
     for (int i = 0; i < nnz; ++i) {
       const float a = fabsf(t_w[i]);
@@ -542,25 +521,58 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
     }
   }
   __syncthreads();
+}
+
+// The block's share of the segments (s0, s0 + s_step, ...) for ONE query whose terms (ascending ids) and weights
+// already sit in sh.t_id / sh.t_w; leaves the block's k best keys in sh.lists[0 .. kListLen) (wave 0's list).
+//
+// Dynamic pruning (exact; the MaxScore idea). A block walks several segments for one query and its lists fill up: once
+// a wave's list holds k keys, the k-th of them is a LOWER bound theta of the final k-th best score. A term t can add
+// at most |w_t| vmax to a row of a segment (vmax: the segment's largest |weight|, in its descriptor), so with the terms
+// ordered by |w_t| the first j of them are NON-ESSENTIAL when (|w_(1)| + .. + |w_(j)|) vmax < theta: a row that shares
+// only such terms with the query cannot reach the top k. Their postings — the long lists of the common terms, which
+// every query of a Zipfian vocabulary carries — are then not read at all: only the ESSENTIAL terms' postings are walked
+// (to mark rows), and every marked row is scored exactly from its own forward (SELL) entries, in ascending id order —
+// the same sum, the same bits. With theta unknown (the first segments of a block, or a list that never fills) and for
+// negative thresholds the full accumulation below runs. The sums are rounded up and compared strictly, so a row that
+// ties with theta is never pruned.
+__device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* __restrict__ segs, int n_seg, int s0,
+                                                  int s_step, const uint64_t* __restrict__ keys,
+                                                  const float* __restrict__ vals, int nnz,
+                                                  const uint8_t* __restrict__ mask, int k, const InvForward fw,
+                                                  int seed_ne = -1, uint64_t theta0 = 0ull) {
+  // seed_ne >= 0: the SEED pass of a batched search — every segment takes the pruned path with exactly the terms
+  // t_ord[seed_ne ..] (the few rarest ones) as essential, whatever the lists hold: the k best rows that carry one of them,
+  // scored exactly, give a threshold theta0 that the main pass starts from in every block (see inv_scan_topk_batch).
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t* list = sh.lists + wave * kListLen;
+  float* score = sh.score;
+  uint8_t* hit = sh.hit;
+  const int32_t* t_id = sh.t_id;
+  const float* t_w = sh.t_w;
+  int32_t* t_lo = sh.t_lo;
   for (int s = s0; s < n_seg; s += s_step) {
     const InvSeg seg = segs[s];
     if (seg.count == 0) continue;  // block-uniform
     const uint64_t* kp = keys + seg.off;
     const float* vp = vals + seg.off;
     // theta: the best k-th key any wave of the block holds (block-uniform: the lists are only written between barriers)
-    uint64_t theta_key = 0ull;
+    uint64_t theta_key = theta0;
 #pragma unroll
     for (int w = 0; w < kInvWaves; ++w) {
       const uint64_t kth = sh.lists[w * kListLen + (k - 1)];
       theta_key = kth > theta_key ? kth : theta_key;
     }
     int n_ne = 0;  // non-essential terms: t_ord[0 .. n_ne)
-    if (theta_key != 0ull) {
+    if (seed_ne >= 0) {
+      n_ne = seed_ne;
+    } else if (theta_key != 0ull) {
       const float theta = inv_key_score(theta_key);
       const float vmax = __int_as_float(seg.pad);
       while (n_ne < nnz && sh.t_pre[n_ne] * vmax * 1.00001f < theta) ++n_ne;  // (false for NaN / inf / theta <= 0)
     }
-    if (n_ne > 0) {
+    if (n_ne > 0 && seed_ne < 0) {
       // worth it? Scoring a marked row from the forward index costs about as much as adding thirty postings, so the
       // pruned path must have few rows to mark: judged by the terms' document frequencies (every thread, same result)
       float ess = 0.0f, all = 0.0f;
@@ -571,7 +583,7 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
       }
       if (!(ess * 32.0f < all)) n_ne = 0;
     }
-    if (n_ne > 0) {
+    if (n_ne > 0 || seed_ne >= 0) {
       // ---- pruned: mark the rows the essential terms name, score those rows exactly from the forward index ----
       for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) hit[r] = 0;
       if (threadIdx.x == 0) sh.n_cand = 0;
@@ -736,6 +748,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_kernel(
     sh.t_frac[threadIdx.x] = sparse_term_fraction(id, weights_given, df_keys, df_cnt, df_cap, n_points);
   }
   __syncthreads();
+  inv_order_terms(sh, nnz);
   inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);
   if (threadIdx.x < kListLen) cand[static_cast<int64_t>(blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
@@ -761,8 +774,9 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
     const float* __restrict__ q_frac, const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand,
-    const InvForward fw) {
+    const InvForward fw, int seed, float n_points, const uint64_t* __restrict__ seed_keys) {
   __shared__ InvShared sh;
+  __shared__ int seed_ne_s;
   const int qy = blockIdx.y;
   const int t0 = q_off[qy];
   const int nnz = min(q_off[qy + 1] - t0, kInvMaxTerms);
@@ -773,7 +787,37 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     sh.t_frac[threadIdx.x] = q_frac[t0 + threadIdx.x];
   }
   __syncthreads();
-  if (nnz > 0) inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw);  // block-uniform
+  inv_order_terms(sh, nnz);
+  int seed_ne = -1;
+  if (seed && nnz > 0) {
+    // the seed pass takes the terms of largest |weight| (the rarest) until they are expected to name a few times k
+    // rows; a query whose rarest terms are common ones is not seeded (its main pass finds its own threshold)
+    if (threadIdx.x == 0) {
+      int ne = -1;
+      float rows = 0.0f;
+      const float want = fmaxf(4.0f * k, 64.0f);
+      for (int j = nnz - 1; j >= 0; --j) {  // by descending |weight|
+        rows += sh.t_frac[sh.t_ord[j]] * n_points;
+        if (rows >= want) {
+          ne = j;
+          break;
+        }
+      }
+      if (ne < 0 && rows > 0.0f) ne = 0;       // every term together names fewer rows than wanted: all of them
+      if (!(rows <= 32768.0f)) ne = -1;         // too many rows to score one by one (or unknown statistics)
+      seed_ne_s = ne;
+    }
+    __syncthreads();
+    seed_ne = seed_ne_s;
+    if (seed_ne < 0) {  // block-uniform: no seed for this query
+      if (threadIdx.x < kListLen)
+        cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = 0ull;
+      return;
+    }
+  }
+  const uint64_t theta0 = (!seed && seed_keys) ? seed_keys[static_cast<int64_t>(qy) * k + (k - 1)] : 0ull;
+  if (nnz > 0)  // block-uniform
+    inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw, seed_ne, theta0);
   if (threadIdx.x < kListLen)
     cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
@@ -818,12 +862,27 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
   int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (16384 + nq - 1) / nq)));
   if (const char* v = std::getenv("VR_SPARSE_BATCH_BLOCKS")) gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max(1, atoi(v))));
   gx = std::min(gx, kScanBlocks);
-  VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * gx * kListLen, 0, e->stream));
+  const int gs = std::min(gx, 16);  // blocks per query of the seed pass (a few rows per segment: latency, not work)
+  VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * std::max(gx, gs) * kListLen, 0, e->stream));
+  const InvForward fw{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p};
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
+  // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; their
+  //    k-th key is a lower bound of the final k-th best score (they are real rows with real scores)
+  static const bool seeding = !(std::getenv("VR_SPARSE_SEED") && atoi(std::getenv("VR_SPARSE_SEED")) == 0);
+  const uint64_t* seed_keys = nullptr;
+  if (seeding && !weights_given) {
+    hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
+                       0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
+                       q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, 1, n_points,
+                       static_cast<const uint64_t*>(nullptr));
+    VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
+    seed_keys = out_keys_dev;
+  }
+  // 2. the scan itself: every block starts from its query's seed threshold, so the common terms' postings are not read
+  //    at all from the first segment on (the merge below overwrites the seed keys once the scan has read them)
   hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
                      0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
-                     q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p,
-                     InvForward{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p});
+                     q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, 0, n_points, seed_keys);
   prof_end(e);
   VR_HIP(hipGetLastError());
   return topk_merge_lists(e, e->sp_cand.p, gx, nq, k, out_keys_dev);
