@@ -468,14 +468,15 @@ __device__ __forceinline__ float inv_key_score(uint64_t key) {
 // The exact score of one row for the query in sh.t_id / sh.t_w (ascending ids): the row's own entries are walked in
 // ascending id order and every shared term adds fl(fl(w * v)) to the sum from +0.0 — the forward scan's arithmetic
 // (sparse.hip) and the inverted accumulation's, hence their bits. *hit: the row shares a term with the query.
-__device__ __forceinline__ float inv_row_score(const InvShared& sh, const InvForward& fw, int64_t row, int nnz, bool* hit) {
+__device__ __forceinline__ float inv_row_score(const int32_t* t_id, const float* t_w, const InvForward& fw, int64_t row,
+                                               int nnz, bool* hit) {
   float acc = 0.0f;
   *hit = false;
   const int32_t s = fw.row_slice[row];
   if (s < 0) return acc;
   const SliceDesc d = fw.slices[s];
   const int lane = static_cast<int>(row - d.row_base);
-  const int32_t last = sh.t_id[nnz - 1];
+  const int32_t last = t_id[nnz - 1];
   int qp = 0;
   for (int c = 0; c < d.width / 4; ++c) {
     const int64_t at = d.off + static_cast<int64_t>(c) * 256 + lane * 4;
@@ -489,9 +490,9 @@ __device__ __forceinline__ float inv_row_score(const InvShared& sh, const InvFor
         done = true;
         break;
       }
-      while (qp < nnz && sh.t_id[qp] < id) ++qp;
-      if (qp < nnz && sh.t_id[qp] == id) {
-        acc = __fadd_rn(acc, __fmul_rn(sh.t_w[qp], fw.sval[at + u]));
+      while (qp < nnz && t_id[qp] < id) ++qp;
+      if (qp < nnz && t_id[qp] == id) {
+        acc = __fadd_rn(acc, __fmul_rn(t_w[qp], fw.sval[at + u]));
         *hit = true;
       }
     }
@@ -623,7 +624,7 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
           const int64_t row = static_cast<int64_t>(seg.row_base) + cand[c];
           if (mask[row]) {
             bool shares = false;
-            const float sc = inv_row_score(sh, fw, row, nnz, &shares);
+            const float sc = inv_row_score(sh.t_id, sh.t_w, fw, row, nnz, &shares);
             if (shares) key = topk_make_key(sc, row);
           }
         }
@@ -774,10 +775,12 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
     const float* __restrict__ q_frac, const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand,
-    const InvForward fw, int seed, float n_points, const uint64_t* __restrict__ seed_keys) {
+    const InvForward fw, const uint64_t* __restrict__ seed_keys, const int32_t* __restrict__ need_full) {
   __shared__ InvShared sh;
-  __shared__ int seed_ne_s;
   const int qy = blockIdx.y;
+  const int64_t slot = static_cast<int64_t>(qy) * gridDim.x + blockIdx.x;
+  // (after sparse_inv_pruned_kernel: only the shares it left — its flags — are scanned here; the others keep its lists)
+  if (need_full && !need_full[slot]) return;  // block-uniform
   const int t0 = q_off[qy];
   const int nnz = min(q_off[qy + 1] - t0, kInvMaxTerms);
   sh.lists[threadIdx.x] = 0ull;
@@ -788,38 +791,201 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
   }
   __syncthreads();
   inv_order_terms(sh, nnz);
-  int seed_ne = -1;
-  if (seed && nnz > 0) {
-    // the seed pass takes the terms of largest |weight| (the rarest) until they are expected to name a few times k
-    // rows; a query whose rarest terms are common ones is not seeded (its main pass finds its own threshold)
+  const uint64_t theta0 = seed_keys ? seed_keys[static_cast<int64_t>(qy) * k + (k - 1)] : 0ull;
+  if (nnz > 0)  // block-uniform
+    inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw, -1, theta0);
+  if (threadIdx.x < kListLen) cand[slot * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
+}
+
+// ---- the pruned scan as its own kernel: no block barriers, waves walk segments on their own --------------------------
+//
+// With a threshold known up front (the seed pass below) a query only needs the rows that carry one of its few
+// ESSENTIAL terms (see inv_scan_segments), a handful per segment — and the per-segment loop above, with its barriers
+// and its 4096-row scratch, is then all latency: search, wait, mark, wait, walk, wait, sixteen segments in a row.
+// Here a block is four independent waves; wave w takes the segments w, w + 4, ... of the block's share and for each of
+// them finds the essential terms' runs (64-way searches), appends the rows they name to ITS candidate buffer in LDS and,
+// whenever that fills and at the end, scores 64 candidates at a time from the forward index (one row per lane,
+// inv_row_score: the forward scan's sum, the same bits) into its own top-k list. A row named by two essential terms
+// is scored twice by the same wave; the list refuses a key it already holds. 11 KiB of LDS per block: the waves of many
+// blocks overlap each other's memory round trips.
+//   SEED: the essential terms are the query's rarest ones (no threshold yet): the k best rows that carry one of them
+//         give theta0 = the k-th of their exact scores, a lower bound of the final k-th best score.
+//   main: essential terms from theta0 and the largest |weight| of the block's segments. A block that cannot prune
+//         (no seed, every term essential, or so many marked rows that adding up the postings is cheaper) sets its flag in
+//         `need_full` and leaves its share to sparse_inv_batch_kernel.
+constexpr int kPrunedCand = 512;  // candidate rows a wave buffers
+
+struct InvPrunedShared {
+  int32_t t_id[kInvMaxTerms];
+  float t_w[kInvMaxTerms];
+  float t_frac[kInvMaxTerms];
+  int32_t t_ord[kInvMaxTerms];
+  float t_pre[kInvMaxTerms];
+  uint64_t lists[kInvWaves * kListLen];
+  uint32_t cand[kInvWaves][kPrunedCand];
+  int32_t n_ne;
+  int32_t vmax_bits;
+};
+
+// wave_list_insert that ignores a key the list already holds
+__device__ __forceinline__ void wave_list_insert_unique(uint64_t* list, int k, uint64_t key, int lane) {
+  const uint64_t cur = list[lane];
+  if (__ballot(cur == key)) return;  // wave-uniform
+  const int pos = __popcll(__ballot(cur > key));
+  if (pos >= k) return;
+  const uint64_t prev = __shfl_up(cur, 1);
+  if (lane == pos) list[lane] = key;
+  else if (lane > pos && lane < k) list[lane] = prev;
+}
+
+template <bool SEED>
+__global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
+    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const int32_t* __restrict__ q_off,
+    const int32_t* __restrict__ q_ids, const float* __restrict__ q_w, const float* __restrict__ q_frac,
+    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand_out, const InvForward fw, float n_points,
+    const uint64_t* __restrict__ seed_keys, int32_t* __restrict__ need_full) {
+  __shared__ InvPrunedShared sh;
+  const int qy = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = q_off[qy];
+  const int nnz = min(q_off[qy + 1] - t0, kInvMaxTerms);
+  const int64_t slot = static_cast<int64_t>(qy) * gridDim.x + blockIdx.x;
+  sh.lists[threadIdx.x] = 0ull;
+  if (static_cast<int>(threadIdx.x) < nnz) {
+    sh.t_id[threadIdx.x] = q_ids[t0 + threadIdx.x];
+    sh.t_w[threadIdx.x] = q_w[t0 + threadIdx.x];
+    sh.t_frac[threadIdx.x] = q_frac[t0 + threadIdx.x];
+  }
+  if (threadIdx.x == 0) {
+    sh.n_ne = -1;
+    sh.vmax_bits = 0;
+  }
+  __syncthreads();
+  if (nnz == 0) {  // block-uniform: a query without terms (or one the host serves another way)
+    if (threadIdx.x < kListLen) cand_out[slot * kListLen + threadIdx.x] = 0ull;
+    if (!SEED && threadIdx.x == 0) need_full[slot] = 0;
+    return;
+  }
+  {  // sh.t_ord / sh.t_pre as inv_order_terms makes them
     if (threadIdx.x == 0) {
-      int ne = -1;
+      for (int i = 0; i < nnz; ++i) {
+        const float a = fabsf(sh.t_w[i]);
+        int j = i;
+        while (j > 0 && fabsf(sh.t_w[sh.t_ord[j - 1]]) > a) {
+          sh.t_ord[j] = sh.t_ord[j - 1];
+          --j;
+        }
+        sh.t_ord[j] = i;
+      }
+      float run = 0.0f;
+      for (int j = 0; j < nnz; ++j) {
+        run = (run + fabsf(sh.t_w[sh.t_ord[j]])) * 1.000001f;
+        sh.t_pre[j] = run;
+      }
+    }
+  }
+  const int share = (n_seg - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  if (!SEED) {  // the largest |weight| of this block's segments (non-negative floats order like their bits; NaN bits are larger still)
+    int vb = 0;
+    for (int si = threadIdx.x; si < share; si += kInvWaves * 64) vb = max(vb, segs[blockIdx.x + si * gridDim.x].pad);
+    if (vb) atomicMax(&sh.vmax_bits, vb);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ne = -1;
+    if (SEED) {
+      // the terms of largest |weight| (the rarest) until they are expected to name a few times k rows; a query whose
+      // rarest terms are common ones is not seeded
       float rows = 0.0f;
       const float want = fmaxf(4.0f * k, 64.0f);
-      for (int j = nnz - 1; j >= 0; --j) {  // by descending |weight|
+      for (int j = nnz - 1; j >= 0; --j) {
         rows += sh.t_frac[sh.t_ord[j]] * n_points;
         if (rows >= want) {
           ne = j;
           break;
         }
       }
-      if (ne < 0 && rows > 0.0f) ne = 0;       // every term together names fewer rows than wanted: all of them
-      if (!(rows <= 32768.0f)) ne = -1;         // too many rows to score one by one (or unknown statistics)
-      seed_ne_s = ne;
+      if (ne < 0 && rows > 0.0f) ne = 0;  // all terms together name fewer rows than wanted: all of them
+      if (!(rows <= 32768.0f)) ne = -1;   // too many rows to score one by one (or unknown statistics)
+    } else {
+      const uint64_t theta_key = seed_keys[static_cast<int64_t>(qy) * k + (k - 1)];
+      if (theta_key != 0ull) {
+        const float theta = inv_key_score(theta_key);
+        const float vmax = __int_as_float(sh.vmax_bits);
+        int n = 0;
+        while (n < nnz && sh.t_pre[n] * vmax * 1.00001f < theta) ++n;  // (false for NaN / inf / theta <= 0)
+        float ess = 0.0f, all = 0.0f;
+        for (int j = 0; j < nnz; ++j) {
+          const float f = sh.t_frac[sh.t_ord[j]];
+          all += f;
+          if (j >= n) ess += f;
+        }
+        if (n > 0 && ess * 32.0f < all) ne = n;
+      }
     }
-    __syncthreads();
-    seed_ne = seed_ne_s;
-    if (seed_ne < 0) {  // block-uniform: no seed for this query
-      if (threadIdx.x < kListLen)
-        cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = 0ull;
-      return;
+    sh.n_ne = ne;
+  }
+  __syncthreads();
+  const int n_ne = sh.n_ne;
+  if (n_ne < 0) {  // block-uniform: nothing to do here (SEED: no seed for this query; main: the full scan takes this share)
+    if (threadIdx.x < kListLen) cand_out[slot * kListLen + threadIdx.x] = 0ull;
+    if (!SEED && threadIdx.x == 0) need_full[slot] = 1;
+    return;
+  }
+  if (!SEED && threadIdx.x == 0) need_full[slot] = 0;
+
+  uint64_t* list = sh.lists + wave * kListLen;
+  uint32_t* mine = sh.cand[wave];
+  int n_c = 0;  // wave-uniform
+  auto flush = [&]() {
+    for (int c0 = 0; c0 < n_c; c0 += 64) {
+      uint64_t key = 0ull;
+      if (c0 + lane < n_c) {
+        const int64_t row = mine[c0 + lane];
+        if (mask[row]) {
+          bool shares = false;
+          const float sc = inv_row_score(sh.t_id, sh.t_w, fw, row, nnz, &shares);
+          if (shares) key = topk_make_key(sc, row);
+        }
+      }
+      const uint64_t thr = list[k - 1];
+      uint64_t pending = __ballot(key != 0ull && key > thr);
+      while (pending) {
+        const int src = __builtin_ctzll(pending);
+        wave_list_insert_unique(list, k, readlane_u64(key, src), lane);
+        pending &= pending - 1;
+      }
+    }
+    n_c = 0;
+  };
+  for (int si = wave; si < share; si += kInvWaves) {
+    const InvSeg seg = segs[blockIdx.x + si * gridDim.x];
+    if (seg.count == 0) continue;  // wave-uniform
+    const uint64_t* kp = keys + seg.off;
+    for (int e = n_ne; e < nnz; ++e) {
+      const int32_t t = sh.t_id[sh.t_ord[e]];
+      const int lb = inv_wave_lower_bound(kp, seg.count, t, lane);
+      for (int p = lb + lane;; p += 64) {
+        bool in_run = false;
+        uint32_t row = 0;
+        if (p < seg.count) {
+          const uint64_t k2 = kp[p];
+          in_run = inv_term(k2) == t;
+          row = static_cast<uint32_t>(seg.row_base) + static_cast<uint32_t>(k2 & (kInvSegRows - 1));
+        }
+        const uint64_t m = __ballot(in_run);
+        if (m) {
+          if (n_c + 64 > kPrunedCand) flush();
+          if (in_run) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
+          n_c += __popcll(m);
+        }
+        if (m != ~0ull) break;  // the run ended inside (or before) these 64 postings
+      }
     }
   }
-  const uint64_t theta0 = (!seed && seed_keys) ? seed_keys[static_cast<int64_t>(qy) * k + (k - 1)] : 0ull;
-  if (nnz > 0)  // block-uniform
-    inv_scan_segments(sh, segs, n_seg, blockIdx.x, gridDim.x, keys, vals, nnz, mask, k, fw, seed_ne, theta0);
-  if (threadIdx.x < kListLen)
-    cand[(static_cast<int64_t>(qy) * gridDim.x + blockIdx.x) * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
+  flush();
+  block_merge_lists(sh.lists, kListLen, kInvWaves, wave, lane);
+  if (threadIdx.x < kListLen) cand_out[slot * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
 
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
@@ -862,27 +1028,36 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
   int gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max<int64_t>(1, (16384 + nq - 1) / nq)));
   if (const char* v = std::getenv("VR_SPARSE_BATCH_BLOCKS")) gx = static_cast<int>(std::min<int64_t>(e->n_inv_seg, std::max(1, atoi(v))));
   gx = std::min(gx, kScanBlocks);
+  const InvForward fw{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p};
+  const dim3 block(kInvWaves * 64);
+  static const bool seeding = !(std::getenv("VR_SPARSE_SEED") && atoi(std::getenv("VR_SPARSE_SEED")) == 0);
+  const bool pruned = seeding && !weights_given;  // (given weights: the engine does not know the terms' frequencies)
   const int gs = std::min(gx, 16);  // blocks per query of the seed pass (a few rows per segment: latency, not work)
   VR_TRY(e->sp_cand.grow(static_cast<int64_t>(nq) * std::max(gx, gs) * kListLen, 0, e->stream));
-  const InvForward fw{e->row_slice.p, e->slices.p, e->sp_idx.p, e->sp_val.p};
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
-  // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; their
-  //    k-th key is a lower bound of the final k-th best score (they are real rows with real scores)
-  static const bool seeding = !(std::getenv("VR_SPARSE_SEED") && atoi(std::getenv("VR_SPARSE_SEED")) == 0);
   const uint64_t* seed_keys = nullptr;
-  if (seeding && !weights_given) {
-    hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
-                       0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
-                       q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, 1, n_points,
-                       static_cast<const uint64_t*>(nullptr));
+  const int32_t* need_full = nullptr;
+  if (pruned) {
+    // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; the
+    //    k-th of them is a lower bound of the final k-th best score (real rows, real scores)
+    hipLaunchKernelGGL((sparse_inv_pruned_kernel<true>), dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), block, 0,
+                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, q_off_dev, q_ids_dev, q_w_dev,
+                       q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, static_cast<const uint64_t*>(nullptr),
+                       static_cast<int32_t*>(nullptr));
     VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
     seed_keys = out_keys_dev;
+    // 2. the pruned scan: only the essential terms' postings, from the first segment on; blocks that cannot prune flag
+    //    their share
+    VR_TRY(e->stage_i32b.grow(static_cast<int64_t>(nq) * gx, 0, e->stream));
+    hipLaunchKernelGGL((sparse_inv_pruned_kernel<false>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0,
+                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, q_off_dev, q_ids_dev, q_w_dev,
+                       q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, seed_keys, e->stage_i32b.p);
+    need_full = e->stage_i32b.p;
   }
-  // 2. the scan itself: every block starts from its query's seed threshold, so the common terms' postings are not read
-  //    at all from the first segment on (the merge below overwrites the seed keys once the scan has read them)
-  hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), dim3(kInvWaves * 64),
-                     0, e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev,
-                     q_ids_dev, q_w_dev, q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, 0, n_points, seed_keys);
+  // 3. the full scan (every term's postings added up per segment) of the shares that are left — all of them without a seed
+  hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0, e->stream,
+                     e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
+                     q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, seed_keys, need_full);
   prof_end(e);
   VR_HIP(hipGetLastError());
   return topk_merge_lists(e, e->sp_cand.p, gx, nq, k, out_keys_dev);
