@@ -684,6 +684,10 @@ def main():
     # ---- configs[4]'s query side: all --queries HYBRID top-10 searches in ONE call (dense batch + sparse batch beside
     # it + fusion on the host threads; N > 1: one all_gather for the whole batch, merge on the engine) ---------------
     sq_list = [(q_terms[20 + i, : q_nnz[20 + i]], ones[: q_nnz[20 + i]]) for i in range(args.queries)]
+    if world == 1:  # the batch's sparse queries as ONE CSR triple (offsets, ids, values): host arrays in, host arrays out
+        sq_off = np.zeros(args.queries + 1, np.int64)
+        sq_off[1:] = np.cumsum(q_nnz[20:20 + args.queries])
+        sq_list = (sq_off, np.concatenate([q[0] for q in sq_list]).astype(np.int32), np.ones(int(sq_off[-1]), np.float32))
     hyb_call = ((lambda: searcher.search_hybrid_batch(qb, sq_list, 10, 0.1)) if world > 1
                 else (lambda: engine.search_hybrid_batch(qb, sq_list, 10, 0.1, raw=True)))
     hyb_batched, hyb_dt, recall_hybrid = None, float("nan"), None

@@ -26,6 +26,9 @@ q_terms = bench.stem_hash(torch, bench.zipf_ids(qgen, torch, nq * 6, 30000, dev)
 q_nnz = np.random.default_rng(5).integers(4, 7, size=nq)
 ones = np.ones(8, np.float32)
 sq = [(q_terms[i, : q_nnz[i]], ones[: q_nnz[i]]) for i in range(nq)]
+sq_off = np.zeros(nq + 1, np.int64)
+sq_off[1:] = np.cumsum(q_nnz)
+sq_csr = (sq_off, np.concatenate([q[0] for q in sq]).astype(np.int32), np.ones(int(sq_off[-1]), np.float32))
 
 
 def timed(name, fn, n=reps):
@@ -52,6 +55,7 @@ ms, n, _ = e.profile_read(Engine.PROF_SPARSE_SCAN)
 print(f"  sparse_inv_batch_kernel: {ms / max(n, 1):.3f} ms per launch ({n} launches)")
 e.profile(False)
 timed("hybrid batch limit=10", lambda: e.search_hybrid_batch(qs, sq, 10, 0.1, raw=True))
+timed("hybrid batch limit=10 (CSR in, raw out)", lambda: e.search_hybrid_batch(qs, sq_csr, 10, 0.1, raw=True))
 keys = timed("hybrid keys k=30", lambda: e.search_hybrid_keys(qs, sq, 30))
 g, s, c = timed("merge_keys (1 part)", lambda: e.merge_keys(keys[None], 30))
 g, s, c = g.reshape(nq, 2, 30), s.reshape(nq, 2, 30), c.reshape(nq, 2)

@@ -177,8 +177,14 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
     const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int rb_stride, int n_qc, int nq, int kb8n,
     float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt,
-    __half* __restrict__ tile_ub) {
-  __shared__ uint4 lds[2 * kBStage / 16];  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
+    __half* __restrict__ tile_ub, unsigned long long* __restrict__ stamps) {
+  __shared__ uint4 lds[2 * kBStage / 16];
+  // diagnostics (VR_BATCH_STAMPS=1): every 61st block's thread 0 writes the shader clock at the phase boundaries
+  const bool stamping = stamps != nullptr && blockIdx.x % 61 == 0 && threadIdx.x == 0;
+  unsigned long long* my_stamps = stamps + (blockIdx.x / 61) * 16;
+  int stamp_at = 0;
+#define VR_STAMP() do { if (stamping) my_stamps[stamp_at++] = __builtin_readcyclecounter(); } while (0)
+  VR_STAMP();  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
   // blocks b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart
   const int bid = blockIdx.x;
   const int lane8 = bid & 7, rest = bid >> 3;
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  VR_STAMP();
   for (int kt = 0; kt < nk; ++kt) {
     const uint4* st = lds + (kt & 1) * (kBStage / 16);
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
@@ -258,6 +265,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    VR_STAMP();
   }
 
   // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile.
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
   }
   float run[2] = {-__builtin_inff(), -__builtin_inff()};
   const int nq_pad = n_qc * kBQ;
+  if (stamping && (m8[7].x | 1)) VR_STAMP();  // (after the per-row words have arrived)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t tile = tile0 + 8 * wm + i;
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
         reinterpret_cast<__half*>(lds)[((g * 16 + 8 * wm + i) * kBQ) + (2 * wn + f) * 16 + (lane & 15)] = __float2half_ru(top);
     }
   }
+  VR_STAMP();
   if (PASS == 1 && tile_ub) {
     __syncthreads();
     const int row = threadIdx.x >> 5, part = threadIdx.x & 31;  // 16 tiles x 32 pieces of four queries (8 bytes)
@@ -332,6 +342,8 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
       if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rbi + wm] = v;
     }
   }
+  VR_STAMP();
+#undef VR_STAMP
 }
 
 // ---- instead of a second pass: revisit the few (tile, query) pairs that can hold a candidate ------------------
@@ -597,11 +609,38 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
     VR_HIP(hipMemsetAsync(e->bq_pairs.p + pair_cap, 0, sizeof(int32_t) * static_cast<size_t>(nq), s));
     tile_ub = reinterpret_cast<__half*>(e->bq_tile_ub.p);
   }
+  // VR_BATCH_STAMPS=1 (diagnostics): phase time stamps of a sample of blocks, printed after the call
+  static const bool stamps_on = getenv("VR_BATCH_STAMPS") && atoi(getenv("VR_BATCH_STAMPS")) != 0;
+  unsigned long long* stamps = nullptr;
+  const size_t n_stamp_blocks = grid1 / 61 + 1;
+  if (stamps_on) {
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), n_stamp_blocks * 16 * sizeof(unsigned long long)));
+    VR_HIP(hipMemsetAsync(stamps, 0, n_stamp_blocks * 16 * sizeof(unsigned long long), s));
+  }
   hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid1), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                      reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                      e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb1, stride, n_qc, nq, kb8n, e->bq_best.p,
                      static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                     tile_ub);
+                     tile_ub, stamps);
+  if (stamps_on) {
+    std::vector<unsigned long long> h(n_stamp_blocks * 16);
+    VR_HIP(hipMemcpyAsync(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    VR_HIP(hipStreamSynchronize(s));
+    (void)hipFree(stamps);
+    double sum[16] = {0};
+    int n = 0;
+    const int nk = kb8n / 2;  // K-steps of the kernel (<= 8: stamps fit in 16 slots)
+    for (size_t b = 0; b < n_stamp_blocks; ++b) {
+      const unsigned long long* t = h.data() + b * 16;
+      if (!t[0] || !t[nk + 4]) continue;
+      for (int i = 1; i <= nk + 4; ++i) sum[i] += static_cast<double>(t[i] - t[i - 1]);
+      ++n;
+    }
+    fprintf(stderr, "[batch_scan stamps] %d blocks, cycles per phase: prologue %.0f |", n, n ? sum[1] / n : 0.0);
+    for (int i = 2; i <= nk + 1; ++i) fprintf(stderr, " k%d %.0f", i - 2, n ? sum[i] / n : 0.0);
+    fprintf(stderr, " | row words %.0f | bounds %.0f | fold+store %.0f\n", n ? sum[nk + 2] / n : 0.0, n ? sum[nk + 3] / n : 0.0,
+            n ? sum[nk + 4] / n : 0.0);
+  }
   const uint64_t* kth = nullptr;
   VR_TRY(topk_select(e, e->bq_best.p, 2 * n_rb1, 2 * n_rb1, nq, k, &kth));
   hipLaunchKernelGGL(batch_threshold_kernel, dim3(static_cast<unsigned>((nq + 255) / 256)), dim3(256), 0, s, kth, nq, k,
@@ -610,7 +649,8 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
     hipLaunchKernelGGL((batch_scan_kernel<2>), dim3(grid), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                        reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                        e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, 1, n_qc, nq, kb8n, static_cast<float*>(nullptr),
-                       e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p, static_cast<__half*>(nullptr));
+                       e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p, static_cast<__half*>(nullptr),
+                       static_cast<unsigned long long*>(nullptr));
   } else {
     hipLaunchKernelGGL(batch_flag_kernel, dim3(static_cast<unsigned>((n_cells / 8 + 255) / 256)), dim3(256), 0, s, tile_ub,
                        e->bq_thr.p, n_cells, nq, static_cast<int>(nq_pad), e->bq_pairs.p, e->bq_pairs.p + pair_cap);

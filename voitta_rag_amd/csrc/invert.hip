@@ -34,6 +34,7 @@
 namespace vr {
 
 constexpr int kInvWaves = 4;
+constexpr int kInvMaxSurvivors = 1024;  // rows of a segment the pruned path scores one by one (beyond: the full sum)
 constexpr int kInvGroup = 4;  // terms whose postings a block requests together,
 constexpr int kInvPer = 4;    // postings of each per thread
 constexpr uint64_t kInvTermMask = 0x7FFFFFFFull;
@@ -574,19 +575,25 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
       while (n_ne < nnz && sh.t_pre[n_ne] * vmax * 1.00001f < theta) ++n_ne;  // (false for NaN / inf / theta <= 0)
     }
     if (n_ne > 0 && seed_ne < 0) {
-      // worth it? Scoring a marked row from the forward index costs about as much as adding thirty postings, so the
-      // pruned path must have few rows to mark: judged by the terms' document frequencies (every thread, same result)
+      // worth it? The pruned path adds up the essential terms' postings and scores the survivors one by one; it pays
+      // when the postings it skips are a good part of all of them: judged by the terms' document frequencies
       float ess = 0.0f, all = 0.0f;
       for (int j = 0; j < nnz; ++j) {
         const float f = sh.t_frac[sh.t_ord[j]];
         all += f;
         if (j >= n_ne) ess += f;
       }
-      if (!(ess * 32.0f < all)) n_ne = 0;
+      if (!(ess * 1.5f < all)) n_ne = 0;
     }
     if (n_ne > 0 || seed_ne >= 0) {
-      // ---- pruned: mark the rows the essential terms name, score those rows exactly from the forward index ----
-      for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) hit[r] = 0;
+      // ---- pruned: add up the ESSENTIAL terms' postings only (a partial score per row: an upper bound of the row's
+      // score once the non-essential terms' bound is added), then score exactly — from the forward index — the rows
+      // whose bound still reaches theta. The partial sums only FILTER; the score that is ranked is the full sum in
+      // ascending term order (inv_row_score), the same bits as ever.
+      for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) {
+        score[r] = 0.0f;
+        hit[r] = 0;
+      }
       if (threadIdx.x == 0) sh.n_cand = 0;
       const int n_es = nnz - n_ne;
       for (int j = wave; j < n_es; j += kInvWaves) {
@@ -595,43 +602,60 @@ __device__ __forceinline__ void inv_scan_segments(InvShared& sh, const InvSeg* _
         if (lane == 0) t_lo[i] = lb;
       }
       __syncthreads();
-      for (int j = 0; j < n_es; ++j) {
+      for (int j = 0; j < n_es; ++j) {  // one term at a time: its postings name distinct rows, the next term's may name the same
         const int i = sh.t_ord[n_ne + j];
         const int32_t t = t_id[i];
+        const float w = t_w[i];
         for (int p = t_lo[i] + static_cast<int>(threadIdx.x);; p += kInvWaves * 64) {
           bool in_run = false;
           if (p < seg.count) {
             const uint64_t k2 = kp[p];
             in_run = inv_term(k2) == t;
-            if (in_run) hit[static_cast<int>(k2 & (kInvSegRows - 1))] = 1;
+            if (in_run) {
+              const int r = static_cast<int>(k2 & (kInvSegRows - 1));
+              score[r] += fabsf(w * vp[p]);  // (magnitudes: a bound that no cancellation between terms can spoil)
+              hit[r] = 1;
+            }
           }
           if (!__all(in_run)) break;  // a wave's chunks only move away from the term's run
         }
+        __syncthreads();
       }
-      __syncthreads();
-      int32_t* cand = reinterpret_cast<int32_t*>(score);
+      // survivors: partial + (what the non-essential terms could still add) >= theta, everything rounded up
+      const float theta_f = seed_ne >= 0 ? -__builtin_inff() : inv_key_score(theta_key);
+      const float ne_ub = (n_ne > 0 && seed_ne < 0) ? sh.t_pre[n_ne - 1] * __int_as_float(seg.pad) * 1.00001f : 0.0f;
+      uint16_t* cand = reinterpret_cast<uint16_t*>(sh.tmax);  // room for kInvMaxSurvivors rows
 #pragma unroll
       for (int j = 0; j < kInvSegRows / (kInvWaves * 64); ++j) {
         const int r = static_cast<int>(threadIdx.x) + j * kInvWaves * 64;
-        if (r < seg.nrows && hit[r]) cand[atomicAdd(&sh.n_cand, 1)] = r;
+        if (r < seg.nrows && hit[r]) {
+          const float part = score[r];
+          if (!(part * 1.00001f + ne_ub < theta_f)) {
+            const int at = atomicAdd(&sh.n_cand, 1);
+            if (at < kInvMaxSurvivors) cand[at] = static_cast<uint16_t>(r);
+          }
+        }
       }
       __syncthreads();
       const int n_cand = sh.n_cand;
-      for (int c0 = 0; c0 < n_cand; c0 += kInvWaves * 64) {  // block-uniform trip count (wave_offer is wave-collective)
-        const int c = c0 + static_cast<int>(threadIdx.x);
-        uint64_t key = 0ull;
-        if (c < n_cand) {
-          const int64_t row = static_cast<int64_t>(seg.row_base) + cand[c];
-          if (mask[row]) {
-            bool shares = false;
-            const float sc = inv_row_score(sh.t_id, sh.t_w, fw, row, nnz, &shares);
-            if (shares) key = topk_make_key(sc, row);
+      if (n_cand <= kInvMaxSurvivors) {  // block-uniform
+        for (int c0 = 0; c0 < n_cand; c0 += kInvWaves * 64) {  // block-uniform trip count (wave_offer is wave-collective)
+          const int c = c0 + static_cast<int>(threadIdx.x);
+          uint64_t key = 0ull;
+          if (c < n_cand) {
+            const int64_t row = static_cast<int64_t>(seg.row_base) + cand[c];
+            if (mask[row]) {
+              bool shares = false;
+              const float sc = inv_row_score(sh.t_id, sh.t_w, fw, row, nnz, &shares);
+              if (shares) key = topk_make_key(sc, row);
+            }
           }
+          wave_offer(list, k, key, 0, key != 0ull, lane);
         }
-        wave_offer(list, k, key, 0, key != 0ull, lane);
+        __syncthreads();  // the next segment reads the lists (theta) and clears the accumulators
+        continue;
       }
-      __syncthreads();  // the next segment reads the lists (theta) and clears the marks
-      continue;
+      __syncthreads();  // too many survivors to score one by one: this segment is added up in full below
     }
     for (int r = threadIdx.x; r < kInvSegRows; r += kInvWaves * 64) {
       score[r] = 0.0f;
@@ -814,6 +838,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
 //         (no seed, every term essential, or so many marked rows that adding up the postings is cheaper) sets its flag in
 //         `need_full` and leaves its share to sparse_inv_batch_kernel.
 constexpr int kPrunedCand = 512;  // candidate rows a wave buffers
+constexpr int kSeedStride = 4;    // the seed pass samples every fourth segment
 
 struct InvPrunedShared {
   int32_t t_id[kInvMaxTerms];
@@ -884,7 +909,10 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
       }
     }
   }
-  const int share = (n_seg - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  // the segments this block walks: bx, bx + gx, ... of all of them — or, for the seed pass, of every kSeedStride-th
+  const int seg_step = SEED ? kSeedStride : 1;
+  const int n_units = (n_seg + seg_step - 1) / seg_step;
+  const int share = (n_units - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
   if (!SEED) {  // the largest |weight| of this block's segments (non-negative floats order like their bits; NaN bits are larger still)
     int vb = 0;
     for (int si = threadIdx.x; si < share; si += kInvWaves * 64) vb = max(vb, segs[blockIdx.x + si * gridDim.x].pad);
@@ -896,10 +924,12 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     if (SEED) {
       // the terms of largest |weight| (the rarest) until they are expected to name a few times k rows; a query whose
       // rarest terms are common ones is not seeded
+      // (the seed pass looks at every kSeedStride-th segment only: a k-th best score among a quarter of the rows is
+      // still a lower bound of the final one, a little weaker, at a quarter of the cost)
       float rows = 0.0f;
       const float want = fmaxf(4.0f * k, 64.0f);
       for (int j = nnz - 1; j >= 0; --j) {
-        rows += sh.t_frac[sh.t_ord[j]] * n_points;
+        rows += sh.t_frac[sh.t_ord[j]] * n_points / kSeedStride;
         if (rows >= want) {
           ne = j;
           break;
@@ -959,7 +989,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     n_c = 0;
   };
   for (int si = wave; si < share; si += kInvWaves) {
-    const InvSeg seg = segs[blockIdx.x + si * gridDim.x];
+    const InvSeg seg = segs[(blockIdx.x + si * gridDim.x) * seg_step];
     if (seg.count == 0) continue;  // wave-uniform
     const uint64_t* kp = keys + seg.off;
     for (int e = n_ne; e < nnz; ++e) {

@@ -444,7 +444,12 @@ class Engine:
     # ---- many queries per call (BASELINE configs[4]: 1k batched hybrid queries) -----------------------------------
     @staticmethod
     def _sparse_csr(sparse_queries, nq: int):
-        """[(indices, values)] per query (None / empty = no sparse terms) -> CSR (off int64, idx int32, val f32)."""
+        """[(indices, values)] per query (None / empty = no sparse terms) -> CSR (off int64, idx int32, val f32).
+        A caller that already holds the batch as CSR passes the triple (off, idx, val) itself."""
+        if isinstance(sparse_queries, tuple) and len(sparse_queries) == 3 and not isinstance(sparse_queries[0], (list, tuple)):
+            off, idx, val = (_np(sparse_queries[0], np.int64), _np(sparse_queries[1], np.int32), _np(sparse_queries[2], np.float32))
+            assert off.shape == (nq + 1,) and idx.shape == val.shape == (int(off[-1]),)
+            return off, idx, val
         assert len(sparse_queries) == nq
         off = np.zeros(nq + 1, np.int64)
         idx, val = [], []
@@ -471,7 +476,8 @@ class Engine:
 
     def search_sparse_batch(self, sparse_queries, k: int, flt: SearchFilter | None = None, weights_given: bool = False):
         """nq sparse searches in one call -> list of (rows int64[c], scores f32[c]); bit for bit nq x search_sparse."""
-        nq = len(sparse_queries)
+        csr = isinstance(sparse_queries, tuple) and len(sparse_queries) == 3 and not isinstance(sparse_queries[0], (list, tuple))
+        nq = len(sparse_queries[0]) - 1 if csr else len(sparse_queries)
         if nq == 0:
             return []
         off, idx, val = self._sparse_csr(sparse_queries, nq)
