@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict
     p[2] = qn;
     p[3] = rho_n;
     p[4] = c_fixed;
+    // forming A = s (a dot_a + b dot_b) in f32 costs three roundings (2e-6 is 30x their sum) of s (|a dot_a| + |b dot_b|)
+    // <= |s x8| (|a qa| + |b qb|) (Cauchy-Schwarz) <= (2.01 + 2 |centre|) (1.25 |q|): stored rows have |x| <= 1 + 1e-6,
+    // the shadow holds s x8 ~ x - centre within its residual (itself at most |x - centre|), a qa is q within a sqrt(D) / 2
+    // and |b qb| <= a sqrt(D) / 2 <= 0.126 |q| for D <= 1024. A constant per query instead of four operations per element.
+    p[5] = 2.0e-6f * (2.01f + 2.0f * centre_norm) * 1.25f * qn;
   }
 }
 
@@ -153,14 +158,13 @@ __device__ __forceinline__ void batch_query_consts(const float* __restrict__ p, 
   pa = p[0];
   pb = p[1];
   p1 = (p[2] + p[3]) * 1.0000004f;
-  p2 = (1.001f * p[3] + p[4]) * 1.0000004f;
+  p2 = (1.001f * p[3] + p[4] + p[5]) * 1.0000004f;  // p[5]: the rounding of forming A, bounded per QUERY (batch_prep_kernel)
 }
 __device__ __forceinline__ void batch_bound(float pa, float pb, float p1, float p2, float ss, float ee, int dot_a, int dot_b,
                                             float& score, float& err) {
   const float fa = pa * static_cast<float>(dot_a);
-  const float fb = pb * static_cast<float>(dot_b);
-  score = ss * (fa + fb);
-  err = fmaf(2.0e-6f * ss, fabsf(fa) + fabsf(fb), fmaf(ee, p1, p2));
+  score = ss * fmaf(pb, static_cast<float>(dot_b), fa);
+  err = fmaf(ee, p1, p2);
 }
 
 __device__ __forceinline__ void glds16b(const void* src, void* lds_dst) {
@@ -237,13 +241,17 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
 #pragma unroll
     for (int f = 0; f < 2; ++f) acc[i][f][0] = acc[i][f][1] = i32x4{0, 0, 0, 0};
 
-  stage(0, 0);
+  // The K-steps are taken in an order rotated by the block's place: the integer sums do not care, and the blocks that
+  // share a query chunk — in step with each other, every one asking the same L2 channel for the same lines of the
+  // query image at the same moment — now spread over nk different parts of it.
+  const int rot = rbi % nk;
+  stage(0, rot);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   VR_STAMP();
   for (int kt = 0; kt < nk; ++kt) {
     const uint4* st = lds + (kt & 1) * (kBStage / 16);
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1 + rot) % nk);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint4 bf[2][2];
@@ -285,37 +293,63 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
   float run[2] = {-__builtin_inff(), -__builtin_inff()};
   const int nq_pad = n_qc * kBQ;
   if (stamping && (m8[7].x | 1)) VR_STAMP();  // (after the per-row words have arrived)
+  if (PASS == 1) {
+    // two elements per instruction on the packed-f32 VALU: the lane's two query fragments side by side. A masked row (or
+    // one behind the corpus's end) gets a bias of -inf into its score, so both of its bounds are -inf and no select is needed.
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f32x2 PA = {pa[0], pa[1]}, PB = {pb[0], pb[1]}, P1 = {p1[0], p1[1]}, P2 = {p2[0], p2[1]};
+    f32x2 run2 = {-__builtin_inff(), -__builtin_inff()};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t tile = tile0 + 8 * wm + i;
-    const bool real = tile <= last_tile;  // wave-uniform
-    const int64_t row0 = tile * kTileRows + 4 * g;
-    const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
-    const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
-    const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      float top = -__builtin_inff();  // PASS 1: the largest upper bound among this lane's four rows of the tile
+    for (int i = 0; i < 8; ++i) {
+      const bool real = static_cast<int>(tile0) + 8 * wm + i <= static_cast<int>(last_tile);  // wave-uniform (tiles < 2^28)
+      const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
+      const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
+      const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
+      f32x2 top2 = {-__builtin_inff(), -__builtin_inff()};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float score, err;
-        batch_bound(pa[f], pb[f], p1[f], p2[f], ss[r], ee[r], acc[i][f][0][r], acc[i][f][1][r], score, err);
-        if (PASS == 1) {
-          if (real && mm[r]) {
-            run[f] = fmaxf(run[f], score - err);
-            top = fmaxf(top, score + err);
-          }
-        } else if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
-          const int slot = atomicAdd(cand_cnt + qidx[f], 1);
-          if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
-        }
+        const float bias = (real && mm[r]) ? 0.0f : -__builtin_inff();
+        const f32x2 da = {static_cast<float>(acc[i][0][0][r]), static_cast<float>(acc[i][1][0][r])};
+        const f32x2 db = {static_cast<float>(acc[i][0][1][r]), static_cast<float>(acc[i][1][1][r])};
+        const f32x2 t = __builtin_elementwise_fma(PB, db, PA * da);
+        const f32x2 score = __builtin_elementwise_fma(f32x2{ss[r], ss[r]}, t, f32x2{bias, bias});
+        const f32x2 err = __builtin_elementwise_fma(f32x2{ee[r], ee[r]}, P1, P2);
+        const f32x2 lo = score - err, up = score + err;
+        run2 = __builtin_elementwise_max(run2, lo);
+        top2 = __builtin_elementwise_max(top2, up);
       }
       // the tile's 16 rows are spread over the four lane groups: each leaves its four-row maximum in LDS (free since
       // the last K-tile's barrier) as [group][16 tiles][128 queries] f16 rounded up; they are folded on the way out
       // (cross-lane maxima here — two swizzles per tile and fragment — cost pass 1 a sixth of its time, and so did
       // writing the bounds as 2-byte stores from 16 lanes)
-      if (PASS == 1 && tile_ub)
-        reinterpret_cast<__half*>(lds)[((g * 16 + 8 * wm + i) * kBQ) + (2 * wn + f) * 16 + (lane & 15)] = __float2half_ru(top);
+      if (tile_ub) {
+        __half* dst = reinterpret_cast<__half*>(lds) + ((g * 16 + 8 * wm + i) * kBQ) + (2 * wn) * 16 + (lane & 15);
+        dst[0] = __float2half_ru(top2.x);
+        dst[16] = __float2half_ru(top2.y);
+      }
+    }
+    run[0] = run2.x;
+    run[1] = run2.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t tile = tile0 + 8 * wm + i;
+      const bool real = tile <= last_tile;  // wave-uniform
+      const int64_t row0 = tile * kTileRows + 4 * g;
+      const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
+      const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
+      const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float score, err;
+          batch_bound(pa[f], pb[f], p1[f], p2[f], ss[r], ee[r], acc[i][f][0][r], acc[i][f][1][r], score, err);
+          if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
+            const int slot = atomicAdd(cand_cnt + qidx[f], 1);
+            if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
+          }
+        }
     }
   }
   VR_STAMP();
