@@ -478,23 +478,33 @@ __device__ __forceinline__ float inv_row_score(const int32_t* t_id, const float*
   const SliceDesc d = fw.slices[s];
   const int lane = static_cast<int>(row - d.row_base);
   const int32_t last = t_id[nnz - 1];
+  const int n_chunks = d.width / 4;
+  const int32_t* base = fw.sidx + d.off + lane * 4;
   int qp = 0;
-  for (int c = 0; c < d.width / 4; ++c) {
-    const int64_t at = d.off + static_cast<int64_t>(c) * 256 + lane * 4;
-    const int4 ids = *reinterpret_cast<const int4*>(fw.sidx + at);
-    const int32_t id4[4] = {ids.x, ids.y, ids.z, ids.w};
+  // the row's ids are requested a dozen 16-byte chunks at a time (their addresses depend on nothing but the slice):
+  // one memory round trip for a row of up to 48 entries instead of one per chunk
+  constexpr int kAhead = 12;
+  for (int c0 = 0; c0 < n_chunks; c0 += kAhead) {
+    int4 ids[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u)
+      ids[u] = c0 + u < n_chunks ? *reinterpret_cast<const int4*>(base + static_cast<int64_t>(c0 + u) * 256) : make_int4(-1, -1, -1, -1);
     bool done = false;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int32_t id = id4[u];
-      if (id < 0 || id > last) {  // padding (real ids are a prefix of the row) or beyond the query's last term
-        done = true;
-        break;
-      }
-      while (qp < nnz && t_id[qp] < id) ++qp;
-      if (qp < nnz && t_id[qp] == id) {
-        acc = __fadd_rn(acc, __fmul_rn(t_w[qp], fw.sval[at + u]));
-        *hit = true;
+    for (int u = 0; u < kAhead; ++u) {
+      const int32_t id4[4] = {ids[u].x, ids[u].y, ids[u].z, ids[u].w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int32_t id = id4[v];
+        if (done || id < 0 || id > last) {  // padding (real ids are a prefix of the row) or beyond the query's last term
+          done = true;
+          continue;
+        }
+        while (qp < nnz && t_id[qp] < id) ++qp;
+        if (qp < nnz && t_id[qp] == id) {
+          acc = __fadd_rn(acc, __fmul_rn(t_w[qp], fw.sval[d.off + static_cast<int64_t>(c0 + u) * 256 + lane * 4 + v]));
+          *hit = true;
+        }
       }
     }
     if (done) break;
@@ -850,6 +860,7 @@ struct InvPrunedShared {
   uint32_t cand[kInvWaves][kPrunedCand];
   int32_t n_ne;
   int32_t vmax_bits;
+  float theta;
 };
 
 // wave_list_insert that ignores a key the list already holds
@@ -865,10 +876,10 @@ __device__ __forceinline__ void wave_list_insert_unique(uint64_t* list, int k, u
 
 template <bool SEED>
 __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
-    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const int32_t* __restrict__ q_off,
-    const int32_t* __restrict__ q_ids, const float* __restrict__ q_w, const float* __restrict__ q_frac,
-    const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand_out, const InvForward fw, float n_points,
-    const uint64_t* __restrict__ seed_keys, int32_t* __restrict__ need_full) {
+    const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
+    const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
+    const float* __restrict__ q_frac, const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand_out,
+    const InvForward fw, float n_points, const uint64_t* __restrict__ seed_keys, int32_t* __restrict__ need_full) {
   __shared__ InvPrunedShared sh;
   const int qy = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -950,7 +961,8 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
           all += f;
           if (j >= n) ess += f;
         }
-        if (n > 0 && ess * 32.0f < all) ne = n;
+        if (n > 0 && ess * 12.0f < all) ne = n;  // (a marked row costs about ten postings' worth of loads and compares)
+        sh.theta = theta;
       }
     }
     sh.n_ne = ne;
@@ -992,24 +1004,33 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     const InvSeg seg = segs[(blockIdx.x + si * gridDim.x) * seg_step];
     if (seg.count == 0) continue;  // wave-uniform
     const uint64_t* kp = keys + seg.off;
+    const float* vp = vals + seg.off;
+    const float vmax = __int_as_float(seg.pad);
     for (int e = n_ne; e < nnz; ++e) {
-      const int32_t t = sh.t_id[sh.t_ord[e]];
+      const int i = sh.t_ord[e];
+      const int32_t t = sh.t_id[i];
+      // a posting of this term survives if its own contribution plus everything the query's OTHER terms could add
+      // still reaches theta (no threshold in the seed pass)
+      const float aw = fabsf(sh.t_w[i]);
+      const float others = SEED ? 0.0f : (sh.t_pre[nnz - 1] - aw * 0.999999f) * vmax * 1.00001f;
+      const float theta = SEED ? -__builtin_inff() : sh.theta;
       const int lb = inv_wave_lower_bound(kp, seg.count, t, lane);
       for (int p = lb + lane;; p += 64) {
-        bool in_run = false;
+        bool in_run = false, keep = false;
         uint32_t row = 0;
         if (p < seg.count) {
           const uint64_t k2 = kp[p];
           in_run = inv_term(k2) == t;
           row = static_cast<uint32_t>(seg.row_base) + static_cast<uint32_t>(k2 & (kInvSegRows - 1));
+          keep = in_run && (SEED || !(aw * fabsf(vp[p]) * 1.00001f + others < theta));
         }
-        const uint64_t m = __ballot(in_run);
+        const uint64_t m = __ballot(keep);
         if (m) {
           if (n_c + 64 > kPrunedCand) flush();
-          if (in_run) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
+          if (keep) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
           n_c += __popcll(m);
         }
-        if (m != ~0ull) break;  // the run ended inside (or before) these 64 postings
+        if (__ballot(in_run) != ~0ull) break;  // the run ended inside (or before) these 64 postings
       }
     }
   }
@@ -1071,7 +1092,7 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
     // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; the
     //    k-th of them is a lower bound of the final k-th best score (real rows, real scores)
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<true>), dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), block, 0,
-                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, q_off_dev, q_ids_dev, q_w_dev,
+                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
                        q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, static_cast<const uint64_t*>(nullptr),
                        static_cast<int32_t*>(nullptr));
     VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
@@ -1080,7 +1101,7 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
     //    their share
     VR_TRY(e->stage_i32b.grow(static_cast<int64_t>(nq) * gx, 0, e->stream));
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<false>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0,
-                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, q_off_dev, q_ids_dev, q_w_dev,
+                       e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
                        q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, seed_keys, e->stage_i32b.p);
     need_full = e->stage_i32b.p;
   }
