@@ -16,3 +16,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-150
 find $O/stats -name "*kernel_trace.csv" -delete
 cd $R && VR_BATCH_STAMPS=1 timeout -k 10 200 python scripts/perf_batch.py 1000000 1000 2 2>&1 | grep -v amdgpu.ids | tail -6
+cd $R && VR_SPARSE_DEBUG=1 timeout -k 10 200 python scripts/perf_hybrid_batch.py 1000000 1000 1 2>&1 | grep "sparse batch\]" | sort | uniq -c | head -5

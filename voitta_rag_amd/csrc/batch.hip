@@ -172,8 +172,13 @@ __device__ __forceinline__ void glds16b(const void* src, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// grid: x = row block (256 rows) interleaved with query chunk so that the chunks of one row block run on one
-// XCD back to back (they share the rows through its L2), see the index arithmetic below.
+// Work items: id -> (row block of 256 rows, chunk of 128 queries), interleaved so that the chunks of one row block have ids
+// 8 apart — one XCD under round-robin placement — and run side by side there (they share the rows through its L2), see
+// `decode` below. The blocks are PERSISTENT: block b takes the items b, b + gridDim.x, ... and treats the K-steps of all
+// of them as one stream through the two stage buffers — the first K-step of the next item is requested during the last
+// K-step of the current one, like any other next step, so only a block's very first item pays a prologue, and the stores
+// of an item's epilogue drain under the next item's main loop (one-item blocks: 4k cycles of prologue and 2-3k of drain per
+// 39k-cycle item, phase stamps of round 3 — profiles/r03_batch_scan_stamps.txt).
 // PASS 1: best[q][128-row slab] = max lower bound (slab = row block x wave row). PASS 2: rows with upper bound >= thr[q] -> cand[q][...].
 template <int PASS>
 __global__ __launch_bounds__(512) void batch_scan_kernel(
@@ -181,38 +186,51 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     const float* __restrict__ params, const float* __restrict__ row_err, const float* __restrict__ row_scale,
     const uint8_t* __restrict__ mask, int64_t n_tiles, int n_rb, int rb_stride, int n_qc, int nq, int kb8n,
     float* __restrict__ best, const float* __restrict__ thr, int32_t* __restrict__ cand, int32_t* __restrict__ cand_cnt,
-    __half* __restrict__ tile_ub, unsigned long long* __restrict__ stamps) {
-  __shared__ uint4 lds[2 * kBStage / 16];
-  // diagnostics (VR_BATCH_STAMPS=1): every 61st block's thread 0 writes the shader clock at the phase boundaries
-  const bool stamping = stamps != nullptr && blockIdx.x % 61 == 0 && threadIdx.x == 0;
+    __half* __restrict__ tile_ub, unsigned long long* __restrict__ stamps, int n_ids) {
+  __shared__ uint4 lds[2 * kBStage / 16];  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
+  // diagnostics (VR_BATCH_STAMPS=1): every 61st block's thread 0 writes the shader clock at the phase boundaries of its FIRST item
+  bool stamping = stamps != nullptr && blockIdx.x % 61 == 0 && threadIdx.x == 0;
   unsigned long long* my_stamps = stamps + (blockIdx.x / 61) * 16;
   int stamp_at = 0;
 #define VR_STAMP() do { if (stamping) my_stamps[stamp_at++] = __builtin_readcyclecounter(); } while (0)
-  VR_STAMP();  // the only LDS object (direct-to-LDS loads in flight beside fragment reads)
-  // blocks b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart
-  const int bid = blockIdx.x;
-  const int lane8 = bid & 7, rest = bid >> 3;
-  const int qc = rest % n_qc;
-  const int rbi = (rest / n_qc) * 8 + lane8;  // n_rb row blocks in the grid: every rb_stride-th of the corpus (pass 1 samples)
-  if (rbi >= n_rb) return;  // block-uniform
-  const int rb = rbi * rb_stride;
+  VR_STAMP();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4;
   const int nk = kb8n / 2;  // 128-deep K-tiles (kb8n is even: dim % 128 == 0)
+  const int64_t last_tile = n_tiles - 1;
+  const int nq_pad = n_qc * kBQ;
+  // ids b and b + 8 share an XCD: the n_qc query chunks of a row block get ids 8 apart. n_rb row blocks take part:
+  // every rb_stride-th of the corpus (a sampled pass 1)
+  auto decode = [&](int id, int& rbi_, int& qc_) {
+    const int lane8 = id & 7, rest = id >> 3;
+    qc_ = rest % n_qc;
+    rbi_ = (rest / n_qc) * 8 + lane8;
+  };
+  auto next_item = [&](int id) {  // the next id of this block that names a row block of the corpus
+    for (id += gridDim.x; id < n_ids; id += gridDim.x) {
+      int r, q;
+      decode(id, r, q);
+      if (r < n_rb) return id;
+    }
+    return n_ids;
+  };
+  int id = static_cast<int>(blockIdx.x) - static_cast<int>(gridDim.x);
+  id = next_item(id);
+  if (id >= n_ids) return;  // block-uniform
 
   // staging: wave w moves the 1-KiB blocks (row tile w, w + 8) x (kb8 0, 1) of the shadow and the blocks
-  // (qfrag w) x {a, b} x (kb8 0, 1) of the query images; every block is one wave-wide 16-byte-per-lane load
-  const int64_t tile0 = static_cast<int64_t>(rb) * 16;
-  const int64_t last_tile = n_tiles - 1;
-  const uint4* gA0 = corpus8 + std::min<int64_t>(tile0 + wave, last_tile) * kb8n * 64 + lane;
-  const uint4* gA1 = corpus8 + std::min<int64_t>(tile0 + wave + 8, last_tile) * kb8n * 64 + lane;
-  const int64_t qf = static_cast<int64_t>(qc) * 8 + wave;  // (images are padded to whole chunks of 128 queries)
-  const uint4* gBa = img_a + qf * kb8n * 64 + lane;
-  const uint4* gBb = img_b + qf * kb8n * 64 + lane;
+  // (qfrag w) x {a, b} x (kb8 0, 1) of the query images; every block is one wave-wide 16-byte-per-lane load.
   // LDS image of a stage, in 1-KiB blocks: rows  [tile 0..15][kb 0..1] = block 2 t + c;
   //                                        query [qfrag 0..7][part a, b][kb 0..1] = block 32 + 4 f + 2 p + c
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](int buf, int rbi_, int qc_, int kt) {
+    const int64_t t0 = static_cast<int64_t>(rbi_) * rb_stride * 16;
+    const uint4* gA0 = corpus8 + std::min<int64_t>(t0 + wave, last_tile) * kb8n * 64 + lane;
+    const uint4* gA1 = corpus8 + std::min<int64_t>(t0 + wave + 8, last_tile) * kb8n * 64 + lane;
+    const int64_t qf = static_cast<int64_t>(qc_) * 8 + wave;  // (images are padded to whole chunks of 128 queries)
+    const uint4* gBa = img_a + qf * kb8n * 64 + lane;
+    const uint4* gBb = img_b + qf * kb8n * 64 + lane;
     uint4* d = lds + buf * (kBStage / 16);
     const int k0 = 2 * kt * 64;
     glds16b(gA0 + k0, d + (2 * wave) * 64);
@@ -225,158 +243,174 @@ __global__ __launch_bounds__(512) void batch_scan_kernel(
     glds16b(gBb + k0 + 64, d + (32 + 4 * wave + 3) * 64);
   };
 
-  // the constants of this lane's two queries (needed by the epilogue only; requested now, so that they are there)
-  float pa[2], pb[2], p1[2], p2[2], pthr[2];
-  int qidx[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
-    batch_query_consts(params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams, pa[f], pb[f], p1[f], p2[f]);
-    pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
-  }
-
-  i32x4 acc[8][2][2];  // [row tile of the wave][qfrag of the wave][part a, b]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) acc[i][f][0] = acc[i][f][1] = i32x4{0, 0, 0, 0};
-
-  // The K-steps are taken in an order rotated by the block's place: the integer sums do not care, and the blocks that
-  // share a query chunk — in step with each other, every one asking the same L2 channel for the same lines of the
-  // query image at the same moment — now spread over nk different parts of it.
-  const int rot = rbi % nk;
-  stage(0, rot);
+  int rbi, qc;
+  decode(id, rbi, qc);
+  int step = 0;  // K-steps taken so far: step & 1 is the stage buffer of the next one
+  // The K-steps of an item are taken in an order rotated by its row block: the integer sums do not care, and items that
+  // share a query chunk do not all ask for the same lines of its image at the same moment.
+  stage(0, rbi, qc, rbi % nk);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   VR_STAMP();
-  for (int kt = 0; kt < nk; ++kt) {
-    const uint4* st = lds + (kt & 1) * (kBStage / 16);
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1 + rot) % nk);
+  while (true) {
+    const int rot = rbi % nk;
+    const int64_t tile0 = static_cast<int64_t>(rbi) * rb_stride * 16;
+    const int next_id = next_item(id);
+    int nrbi = 0, nqc = 0;
+    if (next_id < n_ids) decode(next_id, nrbi, nqc);
+    // the constants of this lane's two queries (needed by the epilogue only; requested now, so that they are there)
+    float pa[2], pb[2], p1[2], p2[2], pthr[2];
+    int qidx[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      uint4 bf[2][2];
+    for (int f = 0; f < 2; ++f) {
+      qidx[f] = qc * kBQ + (2 * wn + f) * 16 + (lane & 15);
+      batch_query_consts(params + static_cast<int64_t>(std::min(qidx[f], nq - 1)) * kQParams, pa[f], pb[f], p1[f], p2[f]);
+      pthr[f] = PASS == 2 ? thr[std::min(qidx[f], nq - 1)] : 0.0f;
+    }
+    i32x4 acc[8][2][2];  // [row tile of the wave][qfrag of the wave][part a, b]
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bf[f][p] = st[(32 + 4 * (2 * wn + f) + 2 * p + c) * 64 + lane];
+      for (int f = 0; f < 2; ++f) acc[i][f][0] = acc[i][f][1] = i32x4{0, 0, 0, 0};
+
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      const uint4* st = lds + (step & 1) * (kBStage / 16);
+      if (kt + 1 < nk) stage((step + 1) & 1, rbi, qc, (kt + 1 + rot) % nk);
+      else if (next_id < n_ids) stage((step + 1) & 1, nrbi, nqc, nrbi % nk);  // the next item's first K-step
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint4 af = st[(2 * (8 * wm + i) + c) * 64 + lane];
+      for (int c = 0; c < 2; ++c) {
+        uint4 bf[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int p = 0; p < 2; ++p)
-            acc[i][f][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(&af),
-                                                                 *reinterpret_cast<const i32x4*>(&bf[f][p]),
-                                                                 acc[i][f][p], 0, 0, 0);
+          for (int p = 0; p < 2; ++p) bf[f][p] = st[(32 + 4 * (2 * wn + f) + 2 * p + c) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint4 af = st[(2 * (8 * wm + i) + c) * 64 + lane];
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              acc[i][f][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(&af),
+                                                                   *reinterpret_cast<const i32x4*>(&bf[f][p]),
+                                                                   acc[i][f][p], 0, 0, 0);
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      VR_STAMP();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    VR_STAMP();
-  }
+    // the stage buffer of the item's LAST K-step is free now (every wave is past the barrier); the other one may already
+    // hold the next item's first K-step. The fold of the tile bounds below uses the free one.
+    uint4* fold = lds + ((step - 1) & 1) * (kBStage / 16);
 
-  // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile.
-  // The per-row words of all eight tiles are requested together (clamped addresses, so nothing depends on the
-  // tail test): as a loop with a break in it they were eight round trips to memory, one after the other.
-  const int g = lane >> 4;
-  uchar4 m8[8];
-  float4 e8[8], s8[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t tile = std::min<int64_t>(tile0 + 8 * wm + i, last_tile);
-    const int64_t row0 = tile * kTileRows + 4 * g;
-    m8[i] = *reinterpret_cast<const uchar4*>(mask + row0);
-    e8[i] = *reinterpret_cast<const float4*>(row_err + row0);
-    s8[i] = *reinterpret_cast<const float4*>(row_scale + row0);
-  }
-  float run[2] = {-__builtin_inff(), -__builtin_inff()};
-  const int nq_pad = n_qc * kBQ;
-  if (stamping && (m8[7].x | 1)) VR_STAMP();  // (after the per-row words have arrived)
-  if (PASS == 1) {
-    // two elements per instruction on the packed-f32 VALU: the lane's two query fragments side by side. A masked row (or
-    // one behind the corpus's end) gets a bias of -inf into its score, so both of its bounds are -inf and no select is needed.
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    const f32x2 PA = {pa[0], pa[1]}, PB = {pb[0], pb[1]}, P1 = {p1[0], p1[1]}, P2 = {p2[0], p2[1]};
-    f32x2 run2 = {-__builtin_inff(), -__builtin_inff()};
+    // epilogue. C/D map: query = lane & 15 of the fragment, rows 4 (lane >> 4) + r of the tile.
+    // The per-row words of all eight tiles are requested together (clamped addresses, so nothing depends on the
+    // tail test): as a loop with a break in it they were eight round trips to memory, one after the other.
+    uchar4 m8[8];
+    float4 e8[8], s8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool real = static_cast<int>(tile0) + 8 * wm + i <= static_cast<int>(last_tile);  // wave-uniform (tiles < 2^28)
-      const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
-      const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
-      const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
-      f32x2 top2 = {-__builtin_inff(), -__builtin_inff()};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float bias = (real && mm[r]) ? 0.0f : -__builtin_inff();
-        const f32x2 da = {static_cast<float>(acc[i][0][0][r]), static_cast<float>(acc[i][1][0][r])};
-        const f32x2 db = {static_cast<float>(acc[i][0][1][r]), static_cast<float>(acc[i][1][1][r])};
-        const f32x2 t = __builtin_elementwise_fma(PB, db, PA * da);
-        const f32x2 score = __builtin_elementwise_fma(f32x2{ss[r], ss[r]}, t, f32x2{bias, bias});
-        const f32x2 err = __builtin_elementwise_fma(f32x2{ee[r], ee[r]}, P1, P2);
-        const f32x2 lo = score - err, up = score + err;
-        run2 = __builtin_elementwise_max(run2, lo);
-        top2 = __builtin_elementwise_max(top2, up);
-      }
-      // the tile's 16 rows are spread over the four lane groups: each leaves its four-row maximum in LDS (free since
-      // the last K-tile's barrier) as [group][16 tiles][128 queries] f16 rounded up; they are folded on the way out
-      // (cross-lane maxima here — two swizzles per tile and fragment — cost pass 1 a sixth of its time, and so did
-      // writing the bounds as 2-byte stores from 16 lanes)
-      if (tile_ub) {
-        __half* dst = reinterpret_cast<__half*>(lds) + ((g * 16 + 8 * wm + i) * kBQ) + (2 * wn) * 16 + (lane & 15);
-        dst[0] = __float2half_ru(top2.x);
-        dst[16] = __float2half_ru(top2.y);
-      }
-    }
-    run[0] = run2.x;
-    run[1] = run2.y;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t tile = tile0 + 8 * wm + i;
-      const bool real = tile <= last_tile;  // wave-uniform
+      const int64_t tile = std::min<int64_t>(tile0 + 8 * wm + i, last_tile);
       const int64_t row0 = tile * kTileRows + 4 * g;
-      const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
-      const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
-      const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
+      m8[i] = *reinterpret_cast<const uchar4*>(mask + row0);
+      e8[i] = *reinterpret_cast<const float4*>(row_err + row0);
+      s8[i] = *reinterpret_cast<const float4*>(row_scale + row0);
+    }
+    float run[2] = {-__builtin_inff(), -__builtin_inff()};
+    if (stamping && (m8[7].x | 1)) VR_STAMP();  // (after the per-row words have arrived)
+    if (PASS == 1) {
+      // two elements per instruction on the packed-f32 VALU: the lane's two query fragments side by side. A masked row (or
+      // one behind the corpus's end) gets a bias of -inf into its score, so both of its bounds are -inf and no select is needed.
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      const f32x2 PA = {pa[0], pa[1]}, PB = {pb[0], pb[1]}, P1 = {p1[0], p1[1]}, P2 = {p2[0], p2[1]};
+      f32x2 run2 = {-__builtin_inff(), -__builtin_inff()};
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int i = 0; i < 8; ++i) {
+        const bool real = static_cast<int>(tile0) + 8 * wm + i <= static_cast<int>(last_tile);  // wave-uniform (tiles < 2^28)
+        const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
+        const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
+        const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
+        f32x2 top2 = {-__builtin_inff(), -__builtin_inff()};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float score, err;
-          batch_bound(pa[f], pb[f], p1[f], p2[f], ss[r], ee[r], acc[i][f][0][r], acc[i][f][1][r], score, err);
-          if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
-            const int slot = atomicAdd(cand_cnt + qidx[f], 1);
-            if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
-          }
+          const float bias = (real && mm[r]) ? 0.0f : -__builtin_inff();
+          const f32x2 da = {static_cast<float>(acc[i][0][0][r]), static_cast<float>(acc[i][1][0][r])};
+          const f32x2 db = {static_cast<float>(acc[i][0][1][r]), static_cast<float>(acc[i][1][1][r])};
+          const f32x2 t = __builtin_elementwise_fma(PB, db, PA * da);
+          const f32x2 score = __builtin_elementwise_fma(f32x2{ss[r], ss[r]}, t, f32x2{bias, bias});
+          const f32x2 err = __builtin_elementwise_fma(f32x2{ee[r], ee[r]}, P1, P2);
+          const f32x2 lo = score - err, up = score + err;
+          run2 = __builtin_elementwise_max(run2, lo);
+          top2 = __builtin_elementwise_max(top2, up);
         }
-    }
-  }
-  VR_STAMP();
-  if (PASS == 1 && tile_ub) {
-    __syncthreads();
-    const int row = threadIdx.x >> 5, part = threadIdx.x & 31;  // 16 tiles x 32 pieces of four queries (8 bytes)
-    using h4 = __attribute__((ext_vector_type(4))) _Float16;
-    h4 best4 = reinterpret_cast<const h4*>(lds)[row * 32 + part];
+        // the tile's 16 rows are spread over the four lane groups: each leaves its four-row maximum in LDS as
+        // [group][16 tiles][128 queries] f16 rounded up; they are folded on the way out (cross-lane maxima here — two
+        // swizzles per tile and fragment — cost pass 1 a sixth of its time, and so did writing the bounds as 2-byte
+        // stores from 16 lanes)
+        if (tile_ub) {
+          __half* dst = reinterpret_cast<__half*>(fold) + ((g * 16 + 8 * wm + i) * kBQ) + (2 * wn) * 16 + (lane & 15);
+          dst[0] = __float2half_ru(top2.x);
+          dst[16] = __float2half_ru(top2.y);
+        }
+      }
+      run[0] = run2.x;
+      run[1] = run2.y;
+    } else {
 #pragma unroll
-    for (int gg = 1; gg < 4; ++gg) {
-      const h4 o = reinterpret_cast<const h4*>(lds)[(gg * 16 + row) * 32 + part];
+      for (int i = 0; i < 8; ++i) {
+        const int64_t tile = tile0 + 8 * wm + i;
+        const bool real = tile <= last_tile;  // wave-uniform
+        const int64_t row0 = tile * kTileRows + 4 * g;
+        const unsigned char mm[4] = {m8[i].x, m8[i].y, m8[i].z, m8[i].w};
+        const float ee[4] = {e8[i].x, e8[i].y, e8[i].z, e8[i].w};
+        const float ss[4] = {s8[i].x, s8[i].y, s8[i].z, s8[i].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) best4[j] = o[j] > best4[j] ? o[j] : best4[j];
-    }
-    *reinterpret_cast<h4*>(tile_ub + (tile0 + row) * nq_pad + qc * kBQ + part * 4) = best4;
-  }
-  if (PASS == 1) {
-    // this wave's 128 rows -> one value per query (the four lane groups hold different rows of the same queries)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      float v = run[f];
-      v = fmaxf(v, __shfl_xor(v, 16));
-      v = fmaxf(v, __shfl_xor(v, 32));
-      if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rbi + wm] = v;
+          for (int r = 0; r < 4; ++r) {
+            float score, err;
+            batch_bound(pa[f], pb[f], p1[f], p2[f], ss[r], ee[r], acc[i][f][0][r], acc[i][f][1][r], score, err);
+            if (real && mm[r] && score + err >= pthr[f] && qidx[f] < nq) {
+              const int slot = atomicAdd(cand_cnt + qidx[f], 1);
+              if (slot < kBatchCand) cand[static_cast<int64_t>(qidx[f]) * kBatchCand + slot] = static_cast<int32_t>(row0 + r);
+            }
+          }
+      }
     }
+    VR_STAMP();
+    if (PASS == 1 && tile_ub) {
+      __syncthreads();
+      const int row = threadIdx.x >> 5, part = threadIdx.x & 31;  // 16 tiles x 32 pieces of four queries (8 bytes)
+      using h4 = __attribute__((ext_vector_type(4))) _Float16;
+      h4 best4 = reinterpret_cast<const h4*>(fold)[row * 32 + part];
+#pragma unroll
+      for (int gg = 1; gg < 4; ++gg) {
+        const h4 o = reinterpret_cast<const h4*>(fold)[(gg * 16 + row) * 32 + part];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) best4[j] = o[j] > best4[j] ? o[j] : best4[j];
+      }
+      *reinterpret_cast<h4*>(tile_ub + (tile0 + row) * nq_pad + qc * kBQ + part * 4) = best4;
+    }
+    if (PASS == 1) {
+      // this wave's 128 rows -> one value per query (the four lane groups hold different rows of the same queries)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float v = run[f];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        if (g == 0 && qidx[f] < nq) best[static_cast<int64_t>(qidx[f]) * (2 * n_rb) + 2 * rbi + wm] = v;
+      }
+    }
+    VR_STAMP();
+    stamping = false;  // (the first item only)
+    if (next_id >= n_ids) break;  // block-uniform
+    // the next item's first K-step stages its second one into the buffer the fold above was read from
+    if (PASS == 1 && tile_ub) __syncthreads();
+    id = next_id;
+    rbi = nrbi;
+    qc = nqc;
   }
-  VR_STAMP();
 #undef VR_STAMP
 }
 
@@ -646,16 +680,24 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
   // VR_BATCH_STAMPS=1 (diagnostics): phase time stamps of a sample of blocks, printed after the call
   static const bool stamps_on = getenv("VR_BATCH_STAMPS") && atoi(getenv("VR_BATCH_STAMPS")) != 0;
   unsigned long long* stamps = nullptr;
-  const size_t n_stamp_blocks = grid1 / 61 + 1;
+  const size_t n_stamp_blocks = grid1 / 61 + 1;  // (room for the one-item-per-block grid)
   if (stamps_on) {
     VR_HIP(hipMalloc(reinterpret_cast<void**>(&stamps), n_stamp_blocks * 16 * sizeof(unsigned long long)));
     VR_HIP(hipMemsetAsync(stamps, 0, n_stamp_blocks * 16 * sizeof(unsigned long long), s));
   }
-  hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(grid1), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
+  // persistent blocks: one per CU (128 KiB of LDS each), ids dealt round-robin — a multiple of 8 blocks keeps an id's XCD
+  static const int n_cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return std::max(8, n / 8 * 8);
+  }();
+  static const bool persistent = !(getenv("VR_BATCH_PERSISTENT") && atoi(getenv("VR_BATCH_PERSISTENT")) == 0);
+  const unsigned blocks1 = persistent ? std::min<unsigned>(grid1, static_cast<unsigned>(n_cus)) : grid1;
+  hipLaunchKernelGGL((batch_scan_kernel<1>), dim3(blocks1), dim3(512), 0, s, reinterpret_cast<const uint4*>(e->corpus16.p),
                      reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                      e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb1, stride, n_qc, nq, kb8n, e->bq_best.p,
                      static_cast<const float*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                     tile_ub, stamps);
+                     tile_ub, stamps, static_cast<int>(grid1));
   if (stamps_on) {
     std::vector<unsigned long long> h(n_stamp_blocks * 16);
     VR_HIP(hipMemcpyAsync(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -684,7 +726,7 @@ int batch_search(vr_engine* e, const float* q_dev, int nq, int k, const uint8_t*
                        reinterpret_cast<const uint4*>(img_a), reinterpret_cast<const uint4*>(img_b), e->bq_params.p,
                        e->row_err.p, e->row_scale.p, mask_dev, n_tiles, n_rb, 1, n_qc, nq, kb8n, static_cast<float*>(nullptr),
                        e->bq_thr.p, e->bq_cand.p, e->bq_cnt.p, static_cast<__half*>(nullptr),
-                       static_cast<unsigned long long*>(nullptr));
+                       static_cast<unsigned long long*>(nullptr), static_cast<int>(grid));
   } else {
     hipLaunchKernelGGL(batch_flag_kernel, dim3(static_cast<unsigned>((n_cells / 8 + 255) / 256)), dim3(256), 0, s, tile_ub,
                        e->bq_thr.p, n_cells, nq, static_cast<int>(nq_pad), e->bq_pairs.p, e->bq_pairs.p + pair_cap);

@@ -879,7 +879,8 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     const InvSeg* __restrict__ segs, int n_seg, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ q_off, const int32_t* __restrict__ q_ids, const float* __restrict__ q_w,
     const float* __restrict__ q_frac, const uint8_t* __restrict__ mask, int k, uint64_t* __restrict__ cand_out,
-    const InvForward fw, float n_points, const uint64_t* __restrict__ seed_keys, int32_t* __restrict__ need_full) {
+    const InvForward fw, float n_points, const uint64_t* __restrict__ seed_keys, int32_t* __restrict__ need_full,
+    unsigned long long* __restrict__ dbg) {
   __shared__ InvPrunedShared sh;
   const int qy = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
       if (!(rows <= 32768.0f)) ne = -1;   // too many rows to score one by one (or unknown statistics)
     } else {
       const uint64_t theta_key = seed_keys[static_cast<int64_t>(qy) * k + (k - 1)];
+      if (dbg && theta_key == 0ull) atomicAdd(dbg + 1, 1ull);  // diagnostics (VR_SPARSE_DEBUG=1): no seed
       if (theta_key != 0ull) {
         const float theta = inv_key_score(theta_key);
         const float vmax = __int_as_float(sh.vmax_bits);
@@ -962,6 +964,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
           if (j >= n) ess += f;
         }
         if (n > 0 && ess * 12.0f < all) ne = n;  // (a marked row costs about ten postings' worth of loads and compares)
+        if (dbg) atomicAdd(dbg + (ne >= 0 ? 0 : n == 0 ? 2 : 3), 1ull);  // pruned / every term essential / too many rows to mark
         sh.theta = theta;
       }
     }
@@ -1094,16 +1097,30 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<true>), dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), block, 0,
                        e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
                        q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, static_cast<const uint64_t*>(nullptr),
-                       static_cast<int32_t*>(nullptr));
+                       static_cast<int32_t*>(nullptr), static_cast<unsigned long long*>(nullptr));
     VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
     seed_keys = out_keys_dev;
     // 2. the pruned scan: only the essential terms' postings, from the first segment on; blocks that cannot prune flag
     //    their share
     VR_TRY(e->stage_i32b.grow(static_cast<int64_t>(nq) * gx, 0, e->stream));
+    static const bool debug = std::getenv("VR_SPARSE_DEBUG") && atoi(std::getenv("VR_SPARSE_DEBUG")) != 0;
+    unsigned long long* dbg = nullptr;
+    if (debug) {
+      VR_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 4 * sizeof(unsigned long long)));
+      VR_HIP(hipMemsetAsync(dbg, 0, 4 * sizeof(unsigned long long), e->stream));
+    }
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<false>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0,
                        e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
-                       q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, seed_keys, e->stage_i32b.p);
+                       q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, seed_keys, e->stage_i32b.p, dbg);
     need_full = e->stage_i32b.p;
+    if (dbg) {
+      unsigned long long h[4] = {0, 0, 0, 0};
+      VR_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+      VR_HIP(hipStreamSynchronize(e->stream));
+      (void)hipFree(dbg);
+      fprintf(stderr, "[sparse batch] %d queries x %d shares: pruned %llu, no seed %llu, every term essential %llu, too many rows %llu\n",
+              nq, gx, h[0], h[1], h[2], h[3]);
+    }
   }
   // 3. the full scan (every term's postings added up per segment) of the shares that are left — all of them without a seed
   hipLaunchKernelGGL(sparse_inv_batch_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0, e->stream,
