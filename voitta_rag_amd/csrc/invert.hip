@@ -849,6 +849,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
 //         `need_full` and leaves its share to sparse_inv_batch_kernel.
 constexpr int kPrunedCand = 512;  // candidate rows a wave buffers
 constexpr int kSeedStride = 4;    // the seed pass samples every fourth segment
+constexpr int kSeedRowsPerWave = 1024;  // ... and a wave scores at most this many rows
 
 struct InvPrunedShared {
   int32_t t_id[kInvMaxTerms];
@@ -948,7 +949,8 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
         }
       }
       if (ne < 0 && rows > 0.0f) ne = 0;  // all terms together name fewer rows than wanted: all of them
-      if (!(rows <= 32768.0f)) ne = -1;   // too many rows to score one by one (or unknown statistics)
+      // (a common "rarest" term names far more rows than a seed needs: every wave stops after kSeedRowsPerWave of them —
+      // any set of real rows gives a valid bound, a smaller set a weaker one)
     } else {
       const uint64_t theta_key = seed_keys[static_cast<int64_t>(qy) * k + (k - 1)];
       if (dbg && theta_key == 0ull) atomicAdd(dbg + 1, 1ull);  // diagnostics (VR_SPARSE_DEBUG=1): no seed
@@ -981,8 +983,10 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
 
   uint64_t* list = sh.lists + wave * kListLen;
   uint32_t* mine = sh.cand[wave];
-  int n_c = 0;  // wave-uniform
+  int n_c = 0;     // wave-uniform
+  int scored = 0;  // rows this wave has scored (the seed pass stops at kSeedRowsPerWave)
   auto flush = [&]() {
+    scored += n_c;
     for (int c0 = 0; c0 < n_c; c0 += 64) {
       uint64_t key = 0ull;
       if (c0 + lane < n_c) {
@@ -1004,6 +1008,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     n_c = 0;
   };
   for (int si = wave; si < share; si += kInvWaves) {
+    if (SEED && scored + n_c >= kSeedRowsPerWave) break;  // wave-uniform
     const InvSeg seg = segs[(blockIdx.x + si * gridDim.x) * seg_step];
     if (seg.count == 0) continue;  // wave-uniform
     const uint64_t* kp = keys + seg.off;
@@ -1034,6 +1039,7 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
           n_c += __popcll(m);
         }
         if (__ballot(in_run) != ~0ull) break;  // the run ended inside (or before) these 64 postings
+        if (SEED && scored + n_c >= kSeedRowsPerWave) break;  // wave-uniform
       }
     }
   }
