@@ -137,14 +137,20 @@ def populate(torch, gen, dev, engine, rows, dim):
     keep = []
     chunk = 100_000
     nnz = 40
-    ar = torch.arange(nnz, device=dev, dtype=torch.int64)[None, :]
     for a in range(0, rows, chunk):
         n = min(chunk, rows - a)
         x = torch.nn.functional.normalize(torch.randn((n, dim), device=dev, generator=gen), dim=1).contiguous()
-        stems = zipf_ids(gen, torch, n * nnz, 30000, dev).view(n, nnz)
-        stems, _ = torch.sort(stems, dim=1)
-        stems = stems * 64 + ar                       # distinct inside a row, still ascending
-        ids, _ = torch.sort(stem_hash(torch, stems).to(torch.int64), dim=1)
+        # BM25 rows over the SAME vocabulary the queries and the timed indexing steps draw from (Zipf(1.07)
+        # over 30,000 words; term id = stem_hash(word)): 40 words per row, a word drawn twice is replaced by a rare one
+        # (ids >= 30000: the long tail every real collection has). Until round 2 the row ids were stem_hash(word * 64 +
+        # position) — a different id space from the queries' stem_hash(word), so most query terms named no row at all.
+        words = zipf_ids(gen, torch, n * nnz, 30000, dev).view(n, nnz)
+        words, _ = torch.sort(words, dim=1)
+        dup = torch.zeros_like(words, dtype=torch.bool)
+        dup[:, 1:] = words[:, 1:] == words[:, :-1]
+        rare = 30000 + torch.randint(0, 1 << 22, (n, nnz), device=dev, generator=gen)
+        words = torch.where(dup, rare, words)
+        ids, _ = torch.sort(stem_hash(torch, words).to(torch.int64), dim=1)
         dup = torch.zeros_like(ids, dtype=torch.bool)
         dup[:, 1:] = ids[:, 1:] == ids[:, :-1]
         ids = torch.where(dup, ids + 1, ids)          # (rare) hash collisions inside a row
