@@ -1023,23 +1023,35 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
       const float others = SEED ? 0.0f : (sh.t_pre[nnz - 1] - aw * 0.999999f) * vmax * 1.00001f;
       const float theta = SEED ? -__builtin_inff() : sh.theta;
       const int lb = inv_wave_lower_bound(kp, seg.count, t, lane);
-      for (int p = lb + lane;; p += 64) {
-        bool in_run = false, keep = false;
-        uint32_t row = 0;
-        if (p < seg.count) {
-          const uint64_t k2 = kp[p];
-          in_run = inv_term(k2) == t;
-          row = static_cast<uint32_t>(seg.row_base) + static_cast<uint32_t>(k2 & (kInvSegRows - 1));
-          keep = in_run && (SEED || !(aw * fabsf(vp[p]) * 1.00001f + others < theta));
+      // the run is walked 4 x 64 postings at a time, all four loads in flight together (most runs end inside the first
+      // round; walked 64 at a time every further 64 cost a memory round trip of their own)
+      bool ended = false;
+      for (int p0 = lb; !ended; p0 += 256) {
+        uint64_t k2[4];
+        float v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + u * 64 + lane;
+          const int pc = p < seg.count ? p : seg.count - 1;  // (count > 0 here; the clamp keeps the loads unconditional)
+          k2[u] = kp[pc];
+          v2[u] = vp[pc];
         }
-        const uint64_t m = __ballot(keep);
-        if (m) {
-          if (n_c + 64 > kPrunedCand) flush();
-          if (keep) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
-          n_c += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ended) break;  // wave-uniform
+          const int p = p0 + u * 64 + lane;
+          const bool in_run = p < seg.count && inv_term(k2[u]) == t;
+          const bool keep = in_run && (SEED || !(aw * fabsf(v2[u]) * 1.00001f + others < theta));
+          const uint32_t row = static_cast<uint32_t>(seg.row_base) + static_cast<uint32_t>(k2[u] & (kInvSegRows - 1));
+          const uint64_t m = __ballot(keep);
+          if (m) {
+            if (n_c + 64 > kPrunedCand) flush();
+            if (keep) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
+            n_c += __popcll(m);
+          }
+          if (__ballot(in_run) != ~0ull) ended = true;  // the run ended inside (or before) these 64 postings
+          if (SEED && scored + n_c >= kSeedRowsPerWave) ended = true;  // wave-uniform
         }
-        if (__ballot(in_run) != ~0ull) break;  // the run ended inside (or before) these 64 postings
-        if (SEED && scored + n_c >= kSeedRowsPerWave) break;  // wave-uniform
       }
     }
   }

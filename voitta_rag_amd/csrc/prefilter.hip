@@ -43,7 +43,6 @@
 
 #include "engine_internal.h"
 #include "topk_device.h"
-#include "merge_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -224,7 +223,7 @@ constexpr int kScan16Waves = 8;
 __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan_kernel(
     const uint4* __restrict__ corpus16, const float* __restrict__ q_img, const float* __restrict__ row_err,
     const uint8_t* __restrict__ mask, int64_t n_tiles, int kb16n, int dim, int k, float* __restrict__ upper,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ counter, uint64_t* __restrict__ thr_keys) {
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counter) {
   extern __shared__ uint4 q_lds[];                                        // [2][kb16n][64] = 2*kb16n KiB
   __shared__ float red[kScan16Waves];
   uint64_t* lists = reinterpret_cast<uint64_t*>(q_lds + 2 * kb16n * 64);  // [waves][kListLen]
@@ -323,9 +322,7 @@ __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan_kernel(
     }
   }
   block_merge_lists(lists, kListLen, kScan16Waves, wave, lane);
-  // the block's k best lower bounds go to cand[block]; the block that arrives LAST merges all of them into thr_keys — the k
-  // best lower bounds of the whole scan, whose k-th is the candidate threshold — instead of a merge launch of its own
-  finish_lists<kScan16Waves * 64>(lists, cand, counter + 2, k, thr_keys);
+  if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = lists[lane];
 }
 
 // ---- stage 1, int8 form ----------------------------------------------------------------------------------
@@ -336,8 +333,7 @@ __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan_kernel(
 __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan8_kernel(
     const uint4* __restrict__ corpus8, const float* __restrict__ q_img, const float* __restrict__ row_err,
     const float* __restrict__ row_scale, const uint8_t* __restrict__ mask, int64_t n_tiles, int kb8n, int dim, int k,
-    float* __restrict__ upper, uint64_t* __restrict__ cand, int32_t* __restrict__ counter, float centre_norm,
-    uint64_t* __restrict__ thr_keys) {
+    float* __restrict__ upper, uint64_t* __restrict__ cand, int32_t* __restrict__ counter, float centre_norm) {
   extern __shared__ uint4 q_lds[];                                        // [2][kb8n][64] = 2*kb8n KiB
   __shared__ float red[3][kScan16Waves];
   uint64_t* lists = reinterpret_cast<uint64_t*>(q_lds + 2 * kb8n * 64);  // [waves][kListLen]
@@ -473,12 +469,10 @@ __global__ __launch_bounds__(kScan16Waves * 64) void prefilter_scan8_kernel(
     }
   }
   block_merge_lists(lists, kListLen, kScan16Waves, wave, lane);
-  // the block's k best lower bounds go to cand[block]; the block that arrives LAST merges all of them into thr_keys — the k
-  // best lower bounds of the whole scan, whose k-th is the candidate threshold — instead of a merge launch of its own
-  finish_lists<kScan16Waves * 64>(lists, cand, counter + 2, k, thr_keys);
+  if (wave == 0) cand[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = lists[lane];
 }
 
-// ---- stages 2 + 3 in one launch: candidates, exact re-score, final ranking ------------------------------------
+// ---- stage 2: candidates = rows whose upper bound reaches the k-th best lower bound ----------------
 
 __device__ __forceinline__ float key_score(uint64_t key) {
   const uint32_t hi = static_cast<uint32_t>(key >> 32);
@@ -486,88 +480,83 @@ __device__ __forceinline__ float key_score(uint64_t key) {
   return __uint_as_float(u);
 }
 
-// thr_keys: the k best lower-bound keys of the scan (descending, zero padded; written by the scan's last workgroup).
-// Block b owns the tiles b, b + gridDim.x, ... (interleaved: a cluster of stored rows that the int8 bounds cannot
-// separate — tens of thousands of candidates in consecutive tiles — is spread over all blocks).
-//   collect  four threads per tile read its sixteen upper bounds; a tile with a row whose bound reaches the threshold
-//            (the k-th best lower bound) goes to the block's list in LDS with its 16-bit row mask. Candidates are kept PER
-//            TILE: rows that crowd together share tiles, and the re-score costs one tile read per tile, not per row.
-//   re-score every listed tile is pulled into LDS by all 16 waves in one memory round trip (with the query image, once),
-//            wave 0 runs dense.hip's MFMA chain over it in k order and offers the exact keys of the masked rows to the
-//            block's top-k list.
-//   finish   the block's list goes out; the block that arrives last merges all lists into out_keys (normally the pinned
-//            result area) and reports the candidate count — no merge launch, no collect launch (round 2: four launches).
-// counter: [0] candidate tiles, [1] candidate rows (both zeroed by the scan kernel), [3] arrivals of this kernel.
-// More than kMaxCandTiles candidate tiles in all (a corpus of near-duplicates): *out_count = INT32_MAX and the host
-// redoes the search with the one-stage scan; blocks that see the budget exceeded skip their re-scoring.
+// lower_keys: the k best lower-bound keys (descending, zero padded). Candidates are gathered PER TILE:
+// tiles[slot] = tile index, masks[slot] = its 16-bit row mask; counter[0] = candidate tiles, counter[1] =
+// candidate rows. The int8 bounds are wide enough that a tight cluster of stored rows can put tens of
+// thousands of rows in play; they share tiles, and stage 3 costs one tile read per TILE, not per row.
+// One float4 of upper bounds per thread (upper[] is padded to a multiple of 64 rows), so the four lanes
+// 4j .. 4j+3 of a wave cover one tile.
+__global__ __launch_bounds__(256) void collect_candidates_kernel(const float* __restrict__ upper, int64_t n,
+                                                                 const uint64_t* __restrict__ lower_keys, int k,
+                                                                 int32_t* __restrict__ tiles,
+                                                                 int32_t* __restrict__ masks, int32_t* counter) {
+  const uint64_t kth = lower_keys[k - 1];
+  // fewer than k rows in play: every row with a finite bound is a candidate
+  const float thr = kth ? key_score(kth) : -3.0e38f;
+  const int lane = threadIdx.x & 63;
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+  float4 u = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+  if (base < n) u = *reinterpret_cast<const float4*>(upper + base);
+  const float uu[4] = {u.x, u.y, u.z, u.w};
+  int m = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (base + c < n && uu[c] >= thr) m |= 1 << c;  // -inf (masked) never passes
+  if (__ballot(m != 0) == 0) return;
+  int m16 = m << (4 * (lane & 3));
+  m16 |= __shfl_xor(m16, 1);
+  m16 |= __shfl_xor(m16, 2);
+  const bool take = (lane & 3) == 0 && m16 != 0;
+  const uint64_t takers = __ballot(take);
+  int rows_here = take ? __popc(m16) : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) rows_here += __shfl_xor(rows_here, off);
+  const int leader = __builtin_ctzll(takers);
+  int slot0 = 0;
+  if (lane == leader) {
+    slot0 = atomicAdd(counter, __popcll(takers));
+    atomicAdd(counter + 1, rows_here);
+  }
+  slot0 = __shfl(slot0, leader);
+  const int slot = slot0 + __popcll(takers & ((1ull << lane) - 1ull));
+  if (take && slot < kMaxCandTiles) {
+    tiles[slot] = static_cast<int32_t>(base / kTileRows);
+    masks[slot] = m16;
+  }
+}
+
+// ---- stage 3: exact re-score + final ranking ---------------------------------------------------------
+
+// Grid-stride over candidate tiles. All 16 waves pull the tile (and, once, the query image) into LDS in
+// one memory round trip — a single wave walking the tile paid one HBM latency per eight k-blocks —
+// then wave 0 runs the same MFMA chain as dense.hip's scan_tile over it, in k order, and offers the
+// exact keys of the masked rows to the block's top-k list. The lists are merged by topk_merge_lists.
 constexpr int kRescoreThreads = 1024;
 constexpr int kRescoreBlocks = 128;
-constexpr int kRescoreChunk = 64;      // k-blocks staged at a time: 2 KiB of LDS each (tile + query)
-constexpr int kRescoreLocal = 1024;    // candidate tiles a block lists (beyond: reported like a blown budget)
+constexpr int kRescoreChunk = 64;  // k-blocks staged at a time: 2 KiB of LDS each (tile + query)
 
 __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(const float4* __restrict__ corpus,
                                                                   const float4* __restrict__ q_img, int kblocks,
-                                                                  const float* __restrict__ upper, int64_t n_rows,
-                                                                  const uint64_t* __restrict__ thr_keys, int k,
-                                                                  int32_t* __restrict__ counter,
+                                                                  const int32_t* __restrict__ tiles,
+                                                                  const int32_t* __restrict__ masks,
+                                                                  const int32_t* __restrict__ counter, int k,
                                                                   uint64_t* __restrict__ lists_out,
-                                                                  uint64_t* __restrict__ out_keys,
                                                                   int32_t* __restrict__ out_count) {
   extern __shared__ float4 stage[];  // [2][chunk][64]
   __shared__ uint64_t best[kListLen];
-  __shared__ int32_t l_tile[kRescoreLocal];
-  __shared__ uint16_t l_mask[kRescoreLocal];
-  __shared__ int32_t n_local, rows_local, skip;
   const int chunk = min(kblocks, kRescoreChunk);
   const bool q_resident = kblocks <= kRescoreChunk;  // one chunk: the query image is staged once
+  const int n_tiles = counter[0];
+  const int count = min(n_tiles, kMaxCandTiles);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n_tiles > kMaxCandTiles ? 0x7fffffff : counter[1];
   if (threadIdx.x < kListLen) best[threadIdx.x] = 0ull;
-  if (threadIdx.x == 0) n_local = rows_local = skip = 0;
-  __syncthreads();
-  // ---- collect
-  const uint64_t kth = thr_keys[k - 1];
-  const float thr = kth ? key_score(kth) : -3.0e38f;  // fewer than k rows in play: every row with a finite bound
-  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  for (int64_t t0 = blockIdx.x; t0 < n_tiles; t0 += static_cast<int64_t>(gridDim.x) * (kRescoreThreads / 4)) {
-    const int64_t tile = t0 + static_cast<int64_t>(threadIdx.x >> 2) * gridDim.x;
-    const int64_t base = tile * kTileRows + (threadIdx.x & 3) * 4;
-    int m = 0;
-    if (tile < n_tiles) {  // (upper[] is padded to a multiple of 64 rows)
-      const float4 u = *reinterpret_cast<const float4*>(upper + base);
-      const float uu[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (base + c < n_rows && uu[c] >= thr) m |= 1 << c;  // -inf (masked) never passes
-    }
-    int m16 = m << (4 * (lane & 3));
-    m16 |= __shfl_xor(m16, 1);
-    m16 |= __shfl_xor(m16, 2);
-    if ((lane & 3) == 0 && m16 != 0) {
-      const int at = atomicAdd(&n_local, 1);
-      atomicAdd(&rows_local, __popc(m16));
-      if (at < kRescoreLocal) {
-        l_tile[at] = static_cast<int32_t>(tile);
-        l_mask[at] = static_cast<uint16_t>(m16);
-      }
-    }
-  }
-  __syncthreads();
-  const int mine = n_local;
-  if (threadIdx.x == 0) {
-    const int before = atomicAdd(counter, mine);
-    atomicAdd(counter + 1, rows_local);
-    skip = before + mine > kMaxCandTiles || mine > kRescoreLocal;
-    if (mine > kRescoreLocal) atomicAdd(counter, kMaxCandTiles);  // (makes the total blow the budget: reported below)
-  }
-  __syncthreads();
-  // ---- re-score
-  const int count = skip ? 0 : mine;
   bool q_staged = !q_resident;  // a resident query image travels with the block's FIRST tile: one memory round trip, not two
   const bool active = (lane & 15) == 0;  // C/D map: column (query) = lane & 15; only query 0 exists
-  for (int c = 0; c < count; ++c) {
-    const int64_t tile = l_tile[c];
-    const int mask = l_mask[c];
+  for (int c = blockIdx.x; c < count; c += gridDim.x) {
+    const int64_t tile = tiles[c];
+    const int mask = masks[c];
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int kb0 = 0; kb0 < kblocks; kb0 += chunk) {
       const int nkb = min(chunk, kblocks - kb0);
@@ -603,12 +592,7 @@ __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(const float4* 
     }
   }
   __syncthreads();
-  // ---- finish: the last block ranks all blocks' lists and reports the candidate count
-  if (finish_lists<kRescoreThreads>(best, lists_out, counter + 3, k, out_keys) && threadIdx.x == 0) {
-    const int tiles = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int rows = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *out_count = tiles > kMaxCandTiles ? 0x7fffffff : rows;
-  }
+  if (wave == 0) lists_out[static_cast<int64_t>(blockIdx.x) * kListLen + lane] = best[lane];
 }
 
 bool prefilter_usable(vr_engine* e, int nq, int k) {
@@ -621,14 +605,11 @@ int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out
   const int kb16n = e->dim / kK16;
   const int64_t n_tiles = (e->n_rows + kTileRows - 1) / kTileRows;
   VR_TRY(e->upper.grow(e->cap_rows, 0, e->stream));
-  if (!e->cand_rows.p) {  // [0] candidate tiles, [1] candidate rows, [2] / [3] arrival counters of the scan / re-score kernels
-    VR_TRY(e->cand_rows.grow(16, 0, e->stream));
-    VR_HIP(hipMemsetAsync(e->cand_rows.p, 0, 16 * sizeof(int32_t), e->stream));
-  }
+  VR_TRY(e->cand_rows.grow(2 * kMaxCandTiles + 16, 0, e->stream));
   int64_t blocks = std::min<int64_t>((n_tiles + kScan16Waves - 1) / kScan16Waves, kScanBlocks);
   VR_TRY(e->cand_a.grow(std::max<int64_t>(blocks, kRescoreBlocks) * kListLen, 0, e->stream));
   VR_TRY(e->cand_b.grow(kListLen, 0, e->stream));
-  int32_t* counter = e->cand_rows.p;
+  int32_t* counter = e->cand_rows.p + 2 * kMaxCandTiles;  // [0] candidate tiles, [1] candidate rows
   hipStream_t s = e->stream;
   if (e->prefilter8) {
     const int kb8n = e->dim / kK8;
@@ -641,7 +622,7 @@ int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out
     hipLaunchKernelGGL(prefilter_scan8_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kScan16Waves * 64), lds, s,
                        reinterpret_cast<const uint4*>(e->corpus16.p), e->q_tiled.p, e->row_err.p, e->row_scale.p,
                        mask_dev, n_tiles, kb8n, e->dim, k, e->upper.p, e->cand_a.p, counter,
-                       e->centre_rows > 0 ? e->centre_norm : 0.0f, e->cand_b.p);
+                       e->centre_rows > 0 ? e->centre_norm : 0.0f);
     prof_end(e);
   } else {
     const size_t lds = static_cast<size_t>(2) * kb16n * 1024 + kScan16Waves * kListLen * sizeof(uint64_t);
@@ -652,16 +633,24 @@ int prefilter_search(vr_engine* e, int k, const uint8_t* mask_dev, uint64_t* out
     prof_begin(e, VR_PROF_DENSE_SCAN, static_cast<double>(e->n_rows) * (e->dim * 2.0 + 4.0 + 1.0 + 4.0));
     hipLaunchKernelGGL(prefilter_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kScan16Waves * 64), lds, s,
                        reinterpret_cast<const uint4*>(e->corpus16.p), e->q_tiled.p, e->row_err.p, mask_dev, n_tiles,
-                       kb16n, e->dim, k, e->upper.p, e->cand_a.p, counter, e->cand_b.p);
+                       kb16n, e->dim, k, e->upper.p, e->cand_a.p, counter);
     prof_end(e);
   }
+  VR_TRY(topk_merge_lists(e, e->cand_a.p, static_cast<int>(blocks), 1, k, e->cand_b.p));
+  const int64_t n4 = (e->n_rows + 3) / 4;
+  int32_t* cand_tiles = e->cand_rows.p;
+  int32_t* cand_masks = e->cand_rows.p + kMaxCandTiles;
+  hipLaunchKernelGGL(collect_candidates_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, s,
+                     e->upper.p, e->n_rows, e->cand_b.p, k, cand_tiles, cand_masks, counter);
   const size_t rescore_lds = static_cast<size_t>(2) * std::min(e->kblocks, kRescoreChunk) * 1024;
-  if (rescore_lds > 32 * 1024)
+  if (rescore_lds > 64 * 1024)
     VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rescore_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rescore_lds)));
   hipLaunchKernelGGL(rescore_kernel, dim3(kRescoreBlocks), dim3(kRescoreThreads), rescore_lds, s,
-                     reinterpret_cast<const float4*>(e->corpus.p), reinterpret_cast<const float4*>(e->q_tiled.p), e->kblocks,
-                     e->upper.p, e->n_rows, e->cand_b.p, k, counter, e->cand_a.p, out_keys_dev, out_count_dev);
+                     reinterpret_cast<const float4*>(e->corpus.p),
+                     reinterpret_cast<const float4*>(e->q_tiled.p), e->kblocks, cand_tiles, cand_masks, counter, k,
+                     e->cand_a.p, out_count_dev);
+  VR_TRY(topk_merge_lists(e, e->cand_a.p, kRescoreBlocks, 1, k, out_keys_dev));
   VR_HIP(hipGetLastError());
   return 0;
 }

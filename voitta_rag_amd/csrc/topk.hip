@@ -11,7 +11,6 @@
 
 #include "engine_internal.h"
 #include "topk_device.h"
-#include "merge_device.h"
 
 namespace vr {
 
@@ -102,11 +101,119 @@ __global__ __launch_bounds__(THREADS) void select_from_keys_kernel(const uint64_
 
 // ---- merging sorted candidate lists ----------------------------------------------------------
 
-// one block per query (the body: merge_device.h)
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeWaves = kMergeThreads / 64;
+constexpr int kMergeMaxLists = 512;                                   // = kScanBlocks
+constexpr int kGatherCap = 2048;  // candidates the fast path ranks in LDS; beyond: tournament
+constexpr int kGatherBatch = 16;  // lists a wave loads at once in the gather pass
+
+// One block per query. The lists are overwritten when the slow path runs.
 __global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(uint64_t* __restrict__ cand, int n_lists,
                                                                      int k, uint64_t* __restrict__ out) {
-  merge_lists_block<false, kMergeThreads>(cand + static_cast<int64_t>(blockIdx.x) * n_lists * kListLen, n_lists, k,
-                           out + static_cast<int64_t>(blockIdx.x) * k);
+  // 20 KiB of LDS only: this kernel must find a CU while a persistent scan of the other search leg
+  // holds most of every CU's LDS (and a kernel with scratch pays ~50 us of dispatch-time setup, so
+  // nothing here may spill either).
+  __shared__ uint64_t gat[kGatherCap];
+  __shared__ uint64_t wave_thr[kMergeWaves];
+  __shared__ uint64_t heads[kMergeMaxLists];
+  __shared__ uint64_t head_thr;
+  __shared__ int gathered;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint64_t* in = cand + static_cast<int64_t>(blockIdx.x) * n_lists * kListLen;
+  uint64_t* dst = out + static_cast<int64_t>(blockIdx.x) * k;
+
+  // Fast path: two lower bounds T of the global k-th key; only keys >= T can be in the answer —
+  // usually k plus a handful. Gather them, rank them.
+  //   (a) the k-th key of ANY list (k keys of that list are at or above it) — good for few long lists;
+  //   (b) the k-th largest list HEAD (k lists start at or above it) — with hundreds of short lists
+  //       this one is close to the true k-th key.
+  // Keys are unique (they carry the row) apart from the empty key 0.
+  {
+    uint64_t t = 0;  // one thread per list (n_lists <= kMergeMaxLists <= kMergeThreads)
+    if (static_cast<int>(threadIdx.x) < n_lists) {
+      heads[threadIdx.x] = in[threadIdx.x * kListLen];
+      t = in[threadIdx.x * kListLen + (k - 1)];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint64_t o = __shfl_xor(t, off);
+      t = o > t ? o : t;
+    }
+    if (lane == 0) wave_thr[wave] = t;
+    if (threadIdx.x == 0) {
+      gathered = 0;
+      head_thr = 0;
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < n_lists) {
+      const uint64_t h = heads[threadIdx.x];
+      int rank = 0;
+      for (int j = 0; j < n_lists; ++j) rank += heads[j] > h;
+      if (rank == k - 1 && h != 0) head_thr = h;
+    }
+    __syncthreads();
+    uint64_t thr = head_thr;
+#pragma unroll
+    for (int w = 0; w < kMergeWaves; ++w) thr = wave_thr[w] > thr ? wave_thr[w] : thr;
+    // a wave takes lists wave, wave + 16, ...; kGatherBatch independent loads are issued together
+    // (a load per iteration behind the LDS atomic serialised one global latency per list)
+    for (int l0 = wave; l0 < n_lists; l0 += kMergeWaves * kGatherBatch) {
+      uint64_t keys[kGatherBatch];
+#pragma unroll
+      for (int u = 0; u < kGatherBatch; ++u) {
+        const int l = min(l0 + u * kMergeWaves, n_lists - 1);  // clamped: the load stays unconditional
+        keys[u] = in[l * kListLen + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < kGatherBatch; ++u) {
+        const uint64_t key = keys[u];
+        const bool take = l0 + u * kMergeWaves < n_lists && lane < k && key != 0 && key >= thr;
+        const uint64_t m = __ballot(take);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&gathered, __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (take && slot < kGatherCap) gat[slot] = key;
+        }
+      }
+    }
+    __syncthreads();
+    const int c = gathered;
+    if (c <= kGatherCap) {  // block-uniform
+      for (int i = threadIdx.x; i < c; i += kMergeThreads) {
+        const uint64_t key = gat[i];
+        int rank = 0;
+        for (int j = 0; j < c; ++j) rank += gat[j] > key;
+        if (rank < k) dst[rank] = key;
+      }
+      for (int i = c + threadIdx.x; i < k; i += kMergeThreads) dst[i] = 0;
+      return;
+    }
+  }
+  // Slow path (rare): a tournament over the lists, in place in global memory, halving their number
+  // per level. Rounds of kMergeWaves pairs: round j reads slots [32j, 32j+32) and writes slots
+  // [16j, 16j+16), which only rounds <= j of this level have read — so one barrier between a round's
+  // reads and its writes is enough, and a wave holds one merged list at a time.
+  int n = n_lists;
+  while (n > 1) {
+    const int pairs = (n + 1) / 2;
+    for (int p0 = 0; p0 < pairs; p0 += kMergeWaves) {
+      const int p = p0 + wave;
+      uint64_t res = 0;
+      if (p < pairs) {
+        const uint64_t a = in[(2 * p) * kListLen + lane];
+        const uint64_t b = (2 * p + 1 < n) ? in[(2 * p + 1) * kListLen + (63 - lane)] : 0ull;
+        res = merge64(a, b, lane);
+      }
+      __syncthreads();
+      if (p < pairs) in[p * kListLen + lane] = res;
+    }
+    __syncthreads();  // (workgroup-scope fence included) the level's lists are visible to every wave
+    n = pairs;
+  }
+  if (wave == 0 && lane < k) dst[lane] = in[lane];
 }
 
 int topk_merge_lists(vr_engine* e, uint64_t* cand, int n_lists, int nq, int k, uint64_t* out) {
