@@ -848,6 +848,8 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_batch_kernel(
 //         (no seed, every term essential, or so many marked rows that adding up the postings is cheaper) sets its flag in
 //         `need_full` and leaves its share to sparse_inv_batch_kernel.
 constexpr int kPrunedCand = 512;  // candidate rows a wave buffers
+constexpr int kPrunedHash = 1024; // slots of a wave's table of essential partial sums (a segment that names more than 3/4 of
+                                  // them distinct rows passes the rest on unfiltered)
 constexpr int kSeedStride = 4;    // the seed pass samples every fourth segment
 constexpr int kSeedRowsPerWave = 1024;  // ... and a wave scores at most this many rows
 
@@ -859,6 +861,9 @@ struct InvPrunedShared {
   float t_pre[kInvMaxTerms];
   uint64_t lists[kInvWaves * kListLen];
   uint32_t cand[kInvWaves][kPrunedCand];
+  // per wave and segment (main pass): the rows the essential terms name with the sum of what those terms add to them
+  // (magnitudes), an open-addressing table; a row survives only if that sum plus the non-essential terms' bound reaches theta
+  // (kInvWaves x kPrunedHash x {uint32 row, float sum} of dynamic LDS, main pass only: the seed pass does not pay for it)
   int32_t n_ne;
   int32_t vmax_bits;
   float theta;
@@ -874,6 +879,8 @@ __device__ __forceinline__ void wave_list_insert_unique(uint64_t* list, int k, u
   if (lane == pos) list[lane] = key;
   else if (lane > pos && lane < k) list[lane] = prev;
 }
+
+extern __shared__ uint32_t inv_pruned_dyn[];
 
 template <bool SEED>
 __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
@@ -965,7 +972,10 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
           all += f;
           if (j >= n) ess += f;
         }
-        if (n > 0 && ess * 12.0f < all) ne = n;  // (a marked row costs about ten postings' worth of loads and compares)
+        // (the essential terms' postings are read and summed per row; only rows whose sum can still reach theta are scored
+        // one by one. Worth it while those postings are a minor part of all of them)
+        // ... and the rows they name fit a wave's table: ~600 of a segment's 4096)
+        if (n > 0 && ess * 3.0f < all && ess < 0.15f) ne = n;
         if (dbg) atomicAdd(dbg + (ne >= 0 ? 0 : n == 0 ? 2 : 3), 1ull);  // pruned / every term essential / too many rows to mark
         sh.theta = theta;
       }
@@ -1014,14 +1024,18 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
     const uint64_t* kp = keys + seg.off;
     const float* vp = vals + seg.off;
     const float vmax = __int_as_float(seg.pad);
+    uint32_t* hrow = inv_pruned_dyn + wave * kPrunedHash;
+    float* hsum = reinterpret_cast<float*>(inv_pruned_dyn + kInvWaves * kPrunedHash) + wave * kPrunedHash;
+    int h_used = 0;  // wave-uniform: distinct rows in the table
+    if (!SEED)
+      for (int j = lane; j < kPrunedHash; j += 64) hrow[j] = 0xFFFFFFFFu;
+    // what the NON-essential terms can add to any row of this segment, rounded up (main pass)
+    const float ne_ub = (!SEED && n_ne > 0) ? sh.t_pre[n_ne - 1] * vmax * 1.00001f : 0.0f;
+    const float theta = SEED ? -__builtin_inff() : sh.theta;
     for (int e = n_ne; e < nnz; ++e) {
       const int i = sh.t_ord[e];
       const int32_t t = sh.t_id[i];
-      // a posting of this term survives if its own contribution plus everything the query's OTHER terms could add
-      // still reaches theta (no threshold in the seed pass)
       const float aw = fabsf(sh.t_w[i]);
-      const float others = SEED ? 0.0f : (sh.t_pre[nnz - 1] - aw * 0.999999f) * vmax * 1.00001f;
-      const float theta = SEED ? -__builtin_inff() : sh.theta;
       const int lb = inv_wave_lower_bound(kp, seg.count, t, lane);
       // the run is walked 4 x 64 postings at a time, all four loads in flight together (most runs end inside the first
       // round; walked 64 at a time every further 64 cost a memory round trip of their own)
@@ -1041,12 +1055,36 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
           if (ended) break;  // wave-uniform
           const int p = p0 + u * 64 + lane;
           const bool in_run = p < seg.count && inv_term(k2[u]) == t;
-          const bool keep = in_run && (SEED || !(aw * fabsf(v2[u]) * 1.00001f + others < theta));
-          const uint32_t row = static_cast<uint32_t>(seg.row_base) + static_cast<uint32_t>(k2[u] & (kInvSegRows - 1));
-          const uint64_t m = __ballot(keep);
+          const uint32_t r12 = static_cast<uint32_t>(k2[u] & (kInvSegRows - 1));
+          bool direct = SEED && in_run;  // (seed pass: every named row is scored)
+          if (!SEED && in_run) {
+            // add |w v| to the row's entry (the postings of ONE term name distinct rows, so the lanes of this instruction
+            // hold distinct rows; two of them may still want the same empty slot: compare-and-swap decides)
+            if (h_used >= kPrunedHash * 3 / 4) {
+              direct = true;  // table full: unfiltered
+            } else {
+              uint32_t h = (r12 * 2654435761u) >> 22;  // 10 bits
+              for (;;) {
+                const uint32_t cur = hrow[h];
+                if (cur == r12) break;
+                if (cur == 0xFFFFFFFFu) {
+                  const uint32_t prev = atomicCAS(&hrow[h], 0xFFFFFFFFu, r12);
+                  if (prev == 0xFFFFFFFFu) {
+                    hsum[h] = 0.0f;
+                    break;
+                  }
+                  if (prev == r12) break;
+                }
+                h = (h + 1) & (kPrunedHash - 1);
+              }
+              hsum[h] += aw * fabsf(v2[u]);
+            }
+          }
+          if (!SEED) h_used += __popcll(__ballot(in_run));  // (an upper bound of the distinct rows: a row of two terms counts twice)
+          const uint64_t m = __ballot(direct);
           if (m) {
             if (n_c + 64 > kPrunedCand) flush();
-            if (keep) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = row;
+            if (direct) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(seg.row_base) + r12;
             n_c += __popcll(m);
           }
           if (__ballot(in_run) != ~0ull) ended = true;  // the run ended inside (or before) these 64 postings
@@ -1054,8 +1092,22 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
         }
       }
     }
+    if (!SEED) {
+      // the rows whose essential sum, with everything the non-essential terms could add, still reaches theta
+      for (int j0 = 0; j0 < kPrunedHash; j0 += 64) {
+        const uint32_t r12 = hrow[j0 + lane];
+        const bool keep = r12 != 0xFFFFFFFFu && !(hsum[j0 + lane] * 1.00001f + ne_ub < theta);
+        const uint64_t m = __ballot(keep);
+        if (m) {
+          if (n_c + 64 > kPrunedCand) flush();
+          if (keep) mine[n_c + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(seg.row_base) + r12;
+          n_c += __popcll(m);
+        }
+      }
+    }
   }
   flush();
+  if (dbg && lane == 0) atomicAdd(dbg + (SEED ? 5 : 4), static_cast<unsigned long long>(scored));  // rows scored one by one
   block_merge_lists(sh.lists, kListLen, kInvWaves, wave, lane);
   if (threadIdx.x < kListLen) cand_out[slot * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
@@ -1109,35 +1161,36 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
   prof_begin(e, VR_PROF_SPARSE_SCAN, 0.0);
   const uint64_t* seed_keys = nullptr;
   const int32_t* need_full = nullptr;
+  static const bool debug = std::getenv("VR_SPARSE_DEBUG") && atoi(std::getenv("VR_SPARSE_DEBUG")) != 0;
+  unsigned long long* dbg = nullptr;
+  if (pruned && debug) {
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 8 * sizeof(unsigned long long)));
+    VR_HIP(hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), e->stream));
+  }
   if (pruned) {
     // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; the
     //    k-th of them is a lower bound of the final k-th best score (real rows, real scores)
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<true>), dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), block, 0,
                        e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
                        q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, static_cast<const uint64_t*>(nullptr),
-                       static_cast<int32_t*>(nullptr), static_cast<unsigned long long*>(nullptr));
+                       static_cast<int32_t*>(nullptr), dbg);
     VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
     seed_keys = out_keys_dev;
     // 2. the pruned scan: only the essential terms' postings, from the first segment on; blocks that cannot prune flag
     //    their share
     VR_TRY(e->stage_i32b.grow(static_cast<int64_t>(nq) * gx, 0, e->stream));
-    static const bool debug = std::getenv("VR_SPARSE_DEBUG") && atoi(std::getenv("VR_SPARSE_DEBUG")) != 0;
-    unsigned long long* dbg = nullptr;
-    if (debug) {
-      VR_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 4 * sizeof(unsigned long long)));
-      VR_HIP(hipMemsetAsync(dbg, 0, 4 * sizeof(unsigned long long), e->stream));
-    }
-    hipLaunchKernelGGL((sparse_inv_pruned_kernel<false>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block, 0,
+    hipLaunchKernelGGL((sparse_inv_pruned_kernel<false>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nq)), block,
+                       static_cast<size_t>(kInvWaves) * kPrunedHash * 8,
                        e->stream, e->inv_seg.p, static_cast<int>(e->n_inv_seg), e->inv_key.p, e->inv_val.p, q_off_dev, q_ids_dev, q_w_dev,
                        q_w_dev + n_terms, mask_dev, k, e->sp_cand.p, fw, n_points, seed_keys, e->stage_i32b.p, dbg);
     need_full = e->stage_i32b.p;
     if (dbg) {
-      unsigned long long h[4] = {0, 0, 0, 0};
+      unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       VR_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, e->stream));
       VR_HIP(hipStreamSynchronize(e->stream));
       (void)hipFree(dbg);
-      fprintf(stderr, "[sparse batch] %d queries x %d shares: pruned %llu, no seed %llu, every term essential %llu, too many rows %llu\n",
-              nq, gx, h[0], h[1], h[2], h[3]);
+      fprintf(stderr, "[sparse batch] %d queries x %d shares: pruned %llu, no seed %llu, every term essential %llu, too many rows %llu; "
+              "rows scored one by one: %llu by the scan, %llu by the seed pass\n", nq, gx, h[0], h[1], h[2], h[3], h[4], h[5]);
     }
   }
   // 3. the full scan (every term's postings added up per segment) of the shares that are left — all of them without a seed
