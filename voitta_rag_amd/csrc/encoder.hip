@@ -170,6 +170,32 @@ __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
   return __builtin_elementwise_fma(hx, w * q, hx);
 }
 
+// Four pairs at once, step by step across the pairs: the same operations per element as gelu_poly2 (same bits), but a
+// dependent v_pk_fma_f32 chain issues one instruction per ~2 issue slots (the compiler pads every step with s_nop 0 and keeps
+// the source order of the four chains): written pair by pair the polynomial of a 16 x 8 epilogue piece was 4 x 11 dependent
+// steps; interleaved, the four chains fill each other's slots.
+__device__ __forceinline__ void gelu_poly2x4(f32x2 (&x)[4]) {
+  constexpr float kClamp = 4.242640495300293f;
+  constexpr float kC[10] = {-5.183208029e-12f, 5.512241219e-10f, -2.635556129e-08f, 7.569865943e-07f, -1.478758622e-05f,
+                            2.114593954e-04f,  -2.317534527e-03f, 1.985279098e-02f,  -1.329084933e-01f, 7.978681326e-01f};
+  f32x2 w[4], s[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = f32x2{__builtin_amdgcn_fmed3f(x[i].x, -kClamp, kClamp), __builtin_amdgcn_fmed3f(x[i].y, -kClamp, kClamp)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = w[i] * w[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(f32x2{kC[0], kC[0]}, s[i], f32x2{kC[1], kC[1]});
+#pragma unroll
+  for (int c = 2; c < 10; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2{kC[c], kC[c]});
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 hx = 0.5f * x[i];
+    x[i] = __builtin_elementwise_fma(hx, w[i] * q[i], hx);
+  }
+}
+
 // Split (hi, lo) matrices live in ONE interleaved array: row r of a [rows][K] matrix is 2K halfs,
 // element k's hi at  r*2K + (k/8)*16 + k%8  and its lo 8 halfs further. A 128-byte line then holds
 // 32 consecutive k of BOTH halves of one row — exactly what a 32-deep GEMM K-tile needs of that row,
@@ -1126,8 +1152,19 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #ifdef VR_GEMM_DIAG_BUILD
 __device__ int g_gemm_diag = 0;
 #define VR_DIAG(bit) ((diag_bits & (bit)) != 0)
+// bit 128: the middle block of the grid stamps s_memtime at six points of each of its first 16 tiles (waves 0 and 4);
+// VR_GEMM_STAMPS=n in the environment prints them for the first n launches (launch_pp)
+__device__ long long g_pp_stamps[2][16][8];
+#define VR_PP_STAMP(slot)                                                                                        \
+  do {                                                                                                           \
+    if (VR_DIAG(128) && stamp_on && tile_seq < 16 && (wave & 3) == 0 && lane == 0)                               \
+      g_pp_stamps[wave >> 2][tile_seq][slot] = __builtin_amdgcn_s_memtime();                                      \
+  } while (0)
 #else
 #define VR_DIAG(bit) false
+#define VR_PP_STAMP(slot) \
+  do {                    \
+  } while (0)
 #endif
 
 constexpr int kWaveStatHalfs = 128 * 4;  // 128 float2 per wave (direct_epilogue's row statistics), in halfs
@@ -1146,14 +1183,20 @@ __device__ __forceinline__ void out_store(T* p, const T& v) {
 #endif
 }
 
-template <int EPI, bool FULL>
+#ifdef VR_GEMM_NO_XPOSE  // (make noxpose: the A/B twin that stores straight from the accumulators, as round 2 did)
+constexpr bool kXposeStores = false;
+#else
+constexpr bool kXposeStores = true;
+#endif
+
+template <int EPI, bool FULL, bool XPOSE = false>
 __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane,
                                                 const float* __restrict__ bias, const float* __restrict__ R,
                                                 float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl,
                                                 int M, int N, float unscale, const float2* __restrict__ ln_stat,
                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                 float2* wave_stat, const float* tile_const = nullptr, int trow0 = 0,
-                                                int tcol0 = 0) {
+                                                int tcol0 = 0, half_t* xpose = nullptr) {
   const int tok = lane & 15, fg = lane >> 4;
 #ifdef VR_GEMM_DIAG_BUILD
   const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
@@ -1164,6 +1207,30 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
   // did not fit next to the accumulators. (A chunk's matrices stay below 4 GiB: kMaxChunkTokens.)
   const uint32_t loff = static_cast<uint32_t>(tok * N + 8 * fg);
   auto upiece = [&](auto* base, int pc, int col) { return base + (static_cast<int64_t>(row0 + 16 * pc) * N + col); };
+  // XPOSE (gemm_f16_pp_kernel; xpose = 4 KiB of the stage buffer the finished K loop has left free, per wave): the f16 rows go out
+  // through a lane exchange. Straight from the accumulators a store instruction has lane (tok, fg) write 16 bytes of token
+  // `tok`: the four lanes of every quad address four different rows, and the store path takes one request per (quad, 64-byte
+  // segment) — 64 per instruction; a lone block needs 4.5 us to get its 128 KiB tile out, 256 blocks together no longer
+  // (scripts/probe_store_burst.hip, profiles/r03_experiments.md §5: the burst is bound per CU by requests, not by HBM).
+  // With the 16 x 4 block of 16-byte pieces transposed — lane L gets token L >> 2, piece L & 3 — a quad writes 64 contiguous
+  // bytes: 16 requests per instruction, the same bytes in 1.35 us. The exchange is one ds_write_b128 + one ds_read_b128 in
+  // a 1-KiB slot only this wave touches (LDS executes a wave's instructions in order: no barrier, no wait in between);
+  // 64-byte rows with piece p of token t at p ^ (t >> 2): both sides conflict-free. The store of a piece is issued one piece
+  // later, so its LDS round trip runs under the next piece's arithmetic.
+  const int xw = tok * 32 + ((fg ^ (tok >> 2)) & 3) * 8;                          // write side, halfs
+  const int xtr = lane >> 2, xtc = lane & 3;
+  const int xr = xtr * 32 + ((xtc ^ (xtr >> 2)) & 3) * 8;                         // read side
+  const uint32_t xloff = static_cast<uint32_t>(xtr * N + 8 * xtc);
+  f16x8 xh = {};
+  int xpend_pc = -1, xpend_p2 = 0;  // (compile-time after unrolling)
+  auto xflush = [&]() {
+    if (FULL) {
+      out_store(reinterpret_cast<f16x8*>(upiece(Ch, xpend_pc, col0 + 32 * xpend_p2) + xloff), xh);
+    } else {
+      const int grow2 = row0 + 16 * xpend_pc + xtr, c2 = col0 + 32 * xpend_p2 + 8 * xtc;
+      if (grow2 < M && c2 < N) out_store(reinterpret_cast<f16x8*>(Ch + static_cast<int64_t>(grow2) * N + c2), xh);
+    }
+  };
   constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
   constexpr bool kStats = EPI == EPI_BIAS_RESIDUAL_LN_STATS || EPI == EPI_RLS_R32_O16 || EPI == EPI_RLS_R16_O16 ||
                           EPI == EPI_RLS_R16_O32;
@@ -1243,13 +1310,21 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
 #pragma unroll
       for (int pc = 0; pc < kAhead; ++pc) fetch_residual(pc, r4[pc], st2[pc]);
     }
+    // (tile constants in LDS: a piece's row statistics are read one piece ahead — every piece is a basic block of its own,
+    // so a read at the point of use cannot be moved up by the compiler and each piece began with an exposed LDS round trip)
+    float2 st_ahead = (kStatUpfront && in_lds) ? lds_stat[tok] : float2{};
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {  // piece pc = token rows 16 pc .. 16 pc + 15 of the wave's 128
       const int grow = row0 + 16 * pc + tok;
       if ((kResidual || kFold) && !kStatUpfront && pc + kAhead < 8)
         fetch_residual(pc + kAhead, r4[(pc + kAhead) % (kAhead + 1)], st2[(pc + kAhead) % (kAhead + 1)]);
       const bool ok = FULL || (grow < M && col_ok);
-      const float2 st = kStatUpfront ? (in_lds ? lds_stat[16 * pc + tok] : st8[pc]) : st2[pc % (kAhead + 1)];
+      const float2 st_lds = st_ahead;
+      if (kStatUpfront && in_lds && pc + 1 < 8) {
+        st_ahead = lds_stat[16 * (pc + 1) + tok];
+        __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks the read to the end of the piece)
+      }
+      const float2 st = kStatUpfront ? (in_lds ? st_lds : st8[pc]) : st2[pc % (kAhead + 1)];
       float v[2][4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1278,11 +1353,13 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
           if (kResidLN) x += ln_apply(rr4[r], st.x, st.y, gg[r], lb[r]);  // residual = LayerNorm(R row)
           v[q][r] = x;
         }
-        if (kGelu && !VR_DIAG(64)) {
-          const f32x2 g01 = gelu_poly2(f32x2{v[q][0], v[q][1]});
-          const f32x2 g23 = gelu_poly2(f32x2{v[q][2], v[q][3]});
-          v[q][0] = g01.x, v[q][1] = g01.y, v[q][2] = g23.x, v[q][3] = g23.y;
-        }
+      }
+      if (kGelu && !VR_DIAG(64)) {
+        f32x2 g[4] = {f32x2{v[0][0], v[0][1]}, f32x2{v[0][2], v[0][3]}, f32x2{v[1][0], v[1][1]}, f32x2{v[1][2], v[1][3]}};
+        gelu_poly2x4(g);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          v[q][0] = g[2 * q].x, v[q][1] = g[2 * q].y, v[q][2] = g[2 * q + 1].x, v[q][3] = g[2 * q + 1].y;
       }
       if (kHalfOut || kStats) {  // f16 row: 8 consecutive features, one 16-byte store
         f16x8 h;
@@ -1293,6 +1370,14 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
         }
         if (VR_DIAG(32)) {
           if (h[0] == static_cast<half_t>(123.0f) && h[7] == static_cast<half_t>(77.0f)) Ch[0] = h[3];  // (keeps the arithmetic alive)
+        } else if (XPOSE) {
+          half_t* slot = xpose + ((8 * p2 + pc) & 3) * 512;
+          *reinterpret_cast<f16x8*>(slot + xw) = h;
+          asm volatile("" ::: "memory");
+          if (xpend_pc >= 0) xflush();
+          xh = *reinterpret_cast<const f16x8*>(slot + xr);
+          asm volatile("" ::: "memory");
+          xpend_pc = pc, xpend_p2 = p2;
         } else if (FULL)
           out_store(reinterpret_cast<f16x8*>(upiece(Ch, pc, col0 + 32 * p2) + loff), h);
         else if (ok)
@@ -1343,8 +1428,98 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
       if (FULL && M < 0) asm volatile("s_nop 0");
     }
   }
+  if (XPOSE && (kHalfOut || kStats) && xpend_pc >= 0) xflush();
 }
 
+
+// Whole tiles of the f16-output projections without residual rows (QKV, FFN-up: four fifths of the bytes the GEMMs write),
+// gemm_f16_pp_kernel only. Same arithmetic per element as direct_epilogue (same bits); what differs is the ORDER of things.
+// In-kernel stamps (make diag, VR_GEMM_DIAG=128, scripts/pp_stamps.sh) showed direct_epilogue's whole-tile path at 9-10k
+// cycles per tile for the QKV variant with its arithmetic switched off as well as on, against 5.4k for the arithmetic
+// alone: every 16-token piece ended in an LDS round trip (lane exchange in front of the store, see direct_epilogue) and
+// began with one (row statistics) that nothing covered — one basic block per piece, lgkmcnt(0) at every block entry.
+// Here four pieces form a batch: their statistics are read together, their f16 rows are written to four LDS slots as they
+// are computed (no wait), then read back transposed together and stored — two exposed LDS round trips per batch of four
+// instead of eight, and the next batch's statistics are requested before the read-back.
+template <int EPI>
+__device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane, half_t* __restrict__ Ch,
+                                                  int M, int N, float unscale, const float* tile_const, int trow0, int tcol0,
+                                                  half_t* xpose) {
+  constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
+  constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
+  const int tok = lane & 15, fg = lane >> 4;
+  const float2* lds_stat = reinterpret_cast<const float2*>(tile_const + 768) + trow0;
+  const int xw = tok * 32 + ((fg ^ (tok >> 2)) & 3) * 8;  // lane exchange: see direct_epilogue (XPOSE)
+  const int xtr = lane >> 2, xtc = lane & 3;
+  const int xr = xtr * 32 + ((xtc ^ (xtr >> 2)) & 3) * 8;
+  const uint32_t xloff = static_cast<uint32_t>(xtr * N + 8 * xtc);
+  float2 st[4] = {};
+  if (kFold) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * i + tok];
+  }
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2) {
+    float4 b4[2], lg4[2] = {};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* tc = tile_const + tcol0 + 32 * p2 + 8 * fg + 4 * q;
+      b4[q] = *reinterpret_cast<const float4*>(tc);
+      if (kFold) lg4[q] = *reinterpret_cast<const float4*>(tc + 256);
+    }
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      float2 stc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stc[i] = st[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pc = 4 * hb + i;
+        float v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+          const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = acc[pc][2 * p2 + q][r];
+            v[q][r] = kFold ? fmaf(fmaf(x, unscale, -(stc[i].x * gg[r])), stc[i].y, bb[r]) : x * unscale + bb[r];
+          }
+        }
+        if (kGelu) {
+          f32x2 g[4] = {f32x2{v[0][0], v[0][1]}, f32x2{v[0][2], v[0][3]}, f32x2{v[1][0], v[1][1]}, f32x2{v[1][2], v[1][3]}};
+          gelu_poly2x4(g);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) v[q][0] = g[2 * q].x, v[q][1] = g[2 * q].y, v[q][2] = g[2 * q + 1].x, v[q][3] = g[2 * q + 1].y;
+        }
+        f16x8 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = static_cast<half_t>(fminf(fmaxf(v[0][r], -65504.0f), 65504.0f));
+          h[4 + r] = static_cast<half_t>(fminf(fmaxf(v[1][r], -65504.0f), 65504.0f));
+        }
+        *reinterpret_cast<f16x8*>(xpose + i * 512 + xw) = h;
+        // (one basic block per piece, as in direct_epilogue: in one long block the SLP vectoriser pairs arithmetic of
+        // different pieces and a thousand registers spill)
+        if (M < 0) asm volatile("s_nop 0");
+      }
+      asm volatile("" ::: "memory");
+      // the next batch's statistics are requested before this one's rows are read back
+      const int nb = 2 * p2 + hb + 1;  // batches 0..3: (p2, hb); the statistics depend on hb only
+      if (kFold && nb < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * (4 * (nb & 1) + i) + tok];
+      }
+      f16x8 xh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xh[i] = *reinterpret_cast<const f16x8*>(xpose + i * 512 + xr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        out_store(reinterpret_cast<f16x8*>(Ch + (static_cast<int64_t>(row0 + 16 * (4 * hb + i)) * N + col0 + 32 * p2) + xloff), xh[i]);
+      asm volatile("" ::: "memory");
+    }
+  }
+}
 
 // ---- the 256x256 f16 product with a ping-pong main loop ----------------------------------------------
 //
@@ -1397,6 +1572,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   float2* wave_stat = reinterpret_cast<float2*>(lds + 2 * kStageHalfs + wave * kWaveStatHalfs);
+  // the epilogue's lane exchange (direct_epilogue: xpose) uses stage buffer 1: the K loop ends on it (nk is even), the next
+  // tile's K-tile 0 is in buffer 0, and nothing loads into buffer 1 before the barrier that follows the epilogue
+  half_t* xpose = lds + kStageHalfs + wave * 2048;
   // the tile's epilogue constants (direct_epilogue: tile_const), fetched by waves 0-4 at the start of the tile's K loop —
   // one direct-to-LDS load each — so that the epilogue starts on LDS reads instead of three rounds of global-load latency
   half_t* tile_const_h = lds + 2 * kStageHalfs + 8 * kWaveStatHalfs;
@@ -1410,7 +1588,10 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
                                EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
   auto issue_tile_consts = [&](int bm_, int bn_) {
     if (!kBranchFree || bm_ + GBM > M || bn_ + GBN > N) return;  // edge tiles read them from global memory (predicated epilogue)
-    const int l8 = lane * 8;  // 16 bytes per lane, in halfs
+    // (the lane offset is made opaque per call: left visible, the compiler keeps five per-lane 64-bit source addresses alive
+    // across the whole kernel — ten registers the epilogue does not have)
+    int l8 = lane * 8;  // 16 bytes per lane, in halfs
+    asm volatile("" : "+v"(l8));
     if (wave == 0) glds16(reinterpret_cast<const half_t*>(bias + bn_) + l8, tile_const_h);
     if (wave == 1 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_g + bn_) + l8, tile_const_h + 512);
     if (wave == 2 && kUsesShift) glds16(reinterpret_cast<const half_t*>(ln_b + bn_) + l8, tile_const_h + 1024);
@@ -1430,12 +1611,26 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   // of quadrant rows 0-63 of both wave rows: "A lo"), 8w + {64, 192} ("A hi"), and W rows
   // 64 (w >> 2) + 8 (w & 3) + {0, 128} (quadrant columns 0-31 of all four wave columns: "W lo"), + {32, 160}
   // ("W hi"): every wave issues two loads per half-tile, so one vmcnt count serves all waves.
-  const int srow = lane >> 3;
-  const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
-  const int ra = wave * 8 + srow;
-  // image rows 64 (w >> 2) + 8 (w & 3) + srow (+ 0, 128, 32, 160): q = (w >> 1) & 1, r = 8 (w & 1) + srow of the
-  // permutation above, i.e. weight row 64 (w >> 2) + 16 (w & 1) + 8 (srow >> 2) + 4 ((w >> 1) & 1) + (srow & 3)
-  const int rwp = 64 * (wave >> 2) + 16 * (wave & 1) + 8 * (srow >> 2) + 4 * ((wave >> 1) & 1) + (srow & 3);
+  // (the per-lane staging and fragment offsets are derived again after every epilogue — derive_lane_state — so that they
+  // do not hold registers while the epilogue runs: it is the kernel's register peak)
+  int schunk, ra, rwp, pa, pw, fk0, fk1;
+  auto derive_lane_state = [&](int lane_) {
+    const int srow = lane_ >> 3;
+    schunk = ((lane_ & 7) ^ ((4 * (wave & 1) + (lane_ >> 4)) & 7)) * 8;
+    ra = wave * 8 + srow;
+    // image rows 64 (w >> 2) + 8 (w & 3) + srow (+ 0, 128, 32, 160): q = (w >> 1) & 1, r = 8 (w & 1) + srow of the
+    // permutation above, i.e. weight row 64 (w >> 2) + 16 (w & 1) + 8 (srow >> 2) + 4 ((w >> 1) & 1) + (srow & 3)
+    rwp = 64 * (wave >> 2) + 16 * (wave & 1) + 8 * (srow >> 2) + 4 * ((wave >> 1) & 1) + (srow & 3);
+    // fragments (v_mfma_f32_16x16x32_f16): lane l supplies row (l & 15), k = 8 (l >> 4) + j of a 32-deep step;
+    // step kk of the K-tile is chunk 4 kk + (l >> 4) of the row, stored at chunk ^ ((row >> 1) & 7)
+    const int frow = lane_ & 15;
+    const int fsw = (frow >> 1) & 7;
+    const int fq = lane_ >> 4;
+    pa = ((wave >> 2) * 128 + frow) * 64;
+    pw = 256 * 64 + ((wave & 3) * 64 + frow) * 64;
+    fk0 = (fq ^ fsw) * 8, fk1 = ((4 + fq) ^ fsw) * 8;
+  };
+  derive_lane_state(lane);
   const half_t *g_a0, *g_a1, *g_a2, *g_a3, *g_w0, *g_w1, *g_w2, *g_w3;
   auto set_ptrs = [&](int bm_, int bn_) {
     g_a0 = Ah + static_cast<int64_t>(min(bm_ + ra, M - 1)) * K + schunk;        // lo
@@ -1456,18 +1651,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
             dw3 = dw0 + 160 * 64;
 
   f32x4 acc[8][4];
-  // fragments (v_mfma_f32_16x16x32_f16): lane l supplies row (l & 15), k = 8 (l >> 4) + j of a 32-deep step;
-  // step kk of the K-tile is chunk 4 kk + (l >> 4) of the row, stored at chunk ^ ((row >> 1) & 7)
-  const int frow = lane & 15;
-  const int fsw = (frow >> 1) & 7;
-  const int fq = lane >> 4;
-  const int pa = (wm * 128 + frow) * 64;
-  const int pw = 256 * 64 + (wn * 64 + frow) * 64;
-  const int fk0 = (fq ^ fsw) * 8, fk1 = ((4 + fq) ^ fsw) * 8;
 
   const int nk = K / 64;  // even
 #ifdef VR_GEMM_DIAG_BUILD
   const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
+  const bool stamp_on = static_cast<int>(blockIdx.x) == G / 2;
+  int tile_seq = 0;
 #endif
 #define VR_PP_BARRIER()                                      \
   do {                                                       \
@@ -1482,6 +1671,15 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 #define VR_PP_VMCNT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+  // Epilogues that issue a known number of stores and no global loads (whole tiles of the branch-free f16-output variants:
+  // constants and row statistics come from LDS): the last two half-tiles of the next tile's K-tile 0 (W hi, A hi, requested
+  // in the last two phases of the K loop) are NOT waited for before the epilogue — their latency runs under its arithmetic —
+  // but by counted waits in the first two phases of the next K loop that let exactly the younger operations (A hi where
+  // it applies, the kEpiStores stores, the phase's own loads) stay in flight. Every other epilogue drains vmcnt first.
+  constexpr bool kTileEpilogue = kXposeStores && (EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU || EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU);
+  constexpr int kEpiStores = (kXposeStores && (EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU || EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU)) ? 16 : -1;
+  bool counted_tail = false;  // block-uniform: the previous tile's epilogue left W hi / A hi to the counted waits
+#define VR_PP_VMCNT_TAIL() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiStores > 0 ? kEpiStores + 4 : 0) : "memory")
 
   // prologue: K-tile 0 of the first tile, all eight pieces, into buffer 0
   glds16(g_a0, lds + da0);
@@ -1505,6 +1703,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const bool has_next = next < total;
     int nbm = bm, nbn = bn;
     if (has_next) coords(next, nbm, nbn);
+    VR_PP_STAMP(0);
 
     // one K-tile out of stage buffer B; the next K-tile (or K-tile 0 of the next tile, or — at the very
     // end — a harmless re-load) goes into buffer B ^ 1
@@ -1534,7 +1733,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         if (!VR_DIAG(8)) af[i][0] = *reinterpret_cast<const f16x8*>(st + pa + i * 16 * 64 + fk0);
         if (!VR_DIAG(8)) af[i][1] = *reinterpret_cast<const f16x8*>(st + pa + i * 16 * 64 + fk1);
       }
-      if (kt != 0) VR_PP_VMCNT4();  // W hi of this K-tile has landed (K-tile 0 was waited for whole)
+      if (kt != 0) VR_PP_VMCNT4();  // W hi of this K-tile has landed (K-tile 0: waited for whole, or by the counted tail)
+      else if (kEpiStores > 0 && counted_tail) VR_PP_VMCNT_TAIL();  // younger: A hi, the stores, this phase's two loads
       VR_PP_BARRIER();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1555,6 +1755,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         if (!VR_DIAG(8)) bf[j][1] = *reinterpret_cast<const f16x8*>(st + pw + (2 + j) * 16 * 64 + fk1);
       }
       if (kt != 0) VR_PP_VMCNT4();  // A hi of this K-tile has landed
+      else if (kEpiStores > 0 && counted_tail) VR_PP_VMCNT_TAIL();  // younger: the stores, the loads of phases 0 and 1
       VR_PP_BARRIER();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1595,6 +1796,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       }
       VR_PP_VMCNT4();  // A lo and W lo of the next K-tile have landed; W hi and A hi stay in flight
       VR_PP_BARRIER();
+      if (kt == 0) VR_PP_STAMP(1);
+      if (kt == 1) VR_PP_STAMP(6);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -1615,33 +1818,55 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     // waves 0-3 are a segment ahead: they wait here for waves 4-7's last MFMA segment, so that all eight waves
     // run the epilogue TOGETHER (one half after the other costs 13 %: each wave's epilogue is bound by the latency of
     // its own loads, and the two waves of a SIMD hide each other's — profiles/r02_gemm_experiments.md §4)
+    VR_PP_STAMP(2);
     if (wm == 0) VR_PP_BARRIER();
     // Epilogue, straight from the accumulators (direct_epilogue).
     // W hi / A hi of the next tile's K-tile 0 may still be in flight: waited for HERE, before this wave's
     // stores queue up behind them (vmcnt retires in order: a counted wait in the next main loop would otherwise
     // wait for the stores too).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool whole_tile = bm + GBM <= M && bn + GBN <= N;  // block-uniform
+    counted_tail = kEpiStores > 0 && whole_tile && !VR_DIAG(2) && !VR_DIAG(32);
+    if (!counted_tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VR_PP_STAMP(3);
     if (!VR_DIAG(2)) {
-    if (kBranchFree && bm + GBM <= M && bn + GBN <= N)  // block-uniform
-      direct_epilogue<EPI, true>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
-                                 reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64);
+    if (kTileEpilogue && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
+      f16_tile_epilogue<EPI>(acc, bm + wm * 128, bn + wn * 64, lane, Ch, M, N, unscale, reinterpret_cast<const float*>(tile_const_h),
+                             wm * 128, wn * 64, xpose);
+    else if (kBranchFree && whole_tile)
+      direct_epilogue<EPI, true, kXposeStores>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
+                                 reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose);
     else
-      direct_epilogue<EPI, false>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat);
+      direct_epilogue<EPI, false, kXposeStores>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
+                                  nullptr, 0, 0, xpose);
     } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
       float t = 0.0f;
       for (int i = 0; i < 8; ++i)
         for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       C[0] = t;
     }
+    VR_PP_STAMP(4);
+#ifdef VR_GEMM_DIAG_BUILD
+    ++tile_seq;
+#endif
     if (!has_next) break;
     tile = next;
     bm = nbm;
     bn = nbn;
+    // the eight staging pointers (16 registers) are dead through the epilogue: they are derived again here, from tile
+    // coordinates the compiler cannot match with the ones the last K-tile used (else it keeps the old values alive)
+    asm volatile("" : "+s"(bm), "+s"(bn));
+    {
+      int lane_again = lane;
+      asm volatile("" : "+v"(lane_again));
+      derive_lane_state(lane_again);
+    }
+    set_ptrs(bm, bn);
     VR_PP_BARRIER();
     if (wm == 1) VR_PP_BARRIER();  // waves 4-7 fall one segment behind again
   }  // tiles
 #undef VR_PP_BARRIER
 #undef VR_PP_VMCNT4
+#undef VR_PP_VMCNT_TAIL
 }
 
 // ---- the f16 product as TWO INDEPENDENT 256x128 tiles per CU ----------------------------------------------
@@ -2114,6 +2339,21 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
     default: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL); break;
   }
 #undef VR_LAUNCH_PP
+#ifdef VR_GEMM_DIAG_BUILD
+  static int stamps_left = getenv("VR_GEMM_STAMPS") ? atoi(getenv("VR_GEMM_STAMPS")) : 0;
+  if (stamps_left > 0) {
+    --stamps_left;
+    (void)hipStreamSynchronize(s);
+    static long long h[2][16][8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_stamps), sizeof(h));
+    fprintf(stderr, "[pp stamps] epi %d M %d N %d K %d: per tile, cycles: main loop (to first new-load wait, to second) | align+wait | epilogue | to next tile\n",
+            epi, M, N, K);
+    for (int w = 0; w < 2; ++w)
+      for (int t = 0; t + 1 < 12; ++t)
+        fprintf(stderr, "  wave %d tile %2d: main %6lld (first %5lld, second %5lld) | %5lld | %6lld | %5lld\n", 4 * w, t, h[w][t][2] - h[w][t][0],
+                h[w][t][1] - h[w][t][0], h[w][t][6] - h[w][t][0], h[w][t][3] - h[w][t][2], h[w][t][4] - h[w][t][3], h[w][t + 1][0] - h[w][t][4]);
+  }
+#endif
 }
 
 // The skinny GEMM of a handful of tokens (M <= 16) with the LayerNorm IN FRONT of it folded in: the
