@@ -1,7 +1,9 @@
 #!/bin/bash
-# In-kernel stamps of gemm_f16_pp_kernel (diag build, `make diag`): one line set per VR_GEMM_DIAG value given
-# usage: scripts/pp_stamps.sh OUT 128 192 160   (128 = stamps; +64 no epilogue arithmetic; +32 no stores)
-export PYTHONPATH=/root/repo VOITTA_ENGINE_LIB=${VOITTA_ENGINE_LIB:-/root/repo/voitta_rag_amd/libvoitta_engine_diag.so}
+# In-kernel stamps of gemm_f16_pp_kernel: `make stamps` (the shipped code path + stamps; give 0 as the only switch value) or
+# `make diag` with VOITTA_ENGINE_LIB=.../libvoitta_engine_diag.so (one line set per VR_GEMM_DIAG value: 64 no epilogue
+# arithmetic, 32 no stores, 1 no loads, 4 no MFMAs, 8 no fragment reads, 16 no barriers)
+# usage: scripts/pp_stamps.sh OUT 0            |   VOITTA_ENGINE_LIB=...diag.so scripts/pp_stamps.sh OUT 0 64 32
+export PYTHONPATH=/root/repo VOITTA_ENGINE_LIB=${VOITTA_ENGINE_LIB:-/root/repo/voitta_rag_amd/libvoitta_engine_stamps.so}
 OUT=$1; shift
 : > $OUT
 for d in "$@"; do

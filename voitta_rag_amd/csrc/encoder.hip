@@ -1152,16 +1152,21 @@ __global__ __launch_bounds__(512) void gemm_f16x3_256_kernel(
 #ifdef VR_GEMM_DIAG_BUILD
 __device__ int g_gemm_diag = 0;
 #define VR_DIAG(bit) ((diag_bits & (bit)) != 0)
-// bit 128: the middle block of the grid stamps s_memtime at six points of each of its first 16 tiles (waves 0 and 4);
-// VR_GEMM_STAMPS=n in the environment prints them for the first n launches (launch_pp)
-__device__ long long g_pp_stamps[2][16][8];
-#define VR_PP_STAMP(slot)                                                                                        \
-  do {                                                                                                           \
-    if (VR_DIAG(128) && stamp_on && tile_seq < 16 && (wave & 3) == 0 && lane == 0)                               \
-      g_pp_stamps[wave >> 2][tile_seq][slot] = __builtin_amdgcn_s_memtime();                                      \
-  } while (0)
 #else
 #define VR_DIAG(bit) false
+#endif
+// Stamp build (make stamps -> libvoitta_engine_stamps.so; the diag build has them too): the shipped code path plus
+// s_memtime stamps — the middle block of the grid, waves 0 and 4, six points of each of its first 16 tiles;
+// VR_GEMM_STAMPS=n in the environment prints them for the first n launches (launch_pp; scripts/pp_stamps.sh).
+#if defined(VR_GEMM_DIAG_BUILD) || defined(VR_GEMM_STAMP_BUILD)
+#define VR_GEMM_HAS_STAMPS 1
+__device__ long long g_pp_stamps[2][16][8];
+#define VR_PP_STAMP(slot)                                                                  \
+  do {                                                                                     \
+    if (stamp_on && tile_seq < 16 && (wave & 3) == 0 && lane == 0)                         \
+      g_pp_stamps[wave >> 2][tile_seq][slot] = __builtin_amdgcn_s_memtime();                \
+  } while (0)
+#else
 #define VR_PP_STAMP(slot) \
   do {                    \
   } while (0)
@@ -1197,6 +1202,7 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                 float2* wave_stat, const float* tile_const = nullptr, int trow0 = 0,
                                                 int tcol0 = 0, half_t* xpose = nullptr) {
+  asm volatile("" : "+v"(lane));  // (lane-derived offsets are made per tile, not carried through the K loop)
   const int tok = lane & 15, fg = lane >> 4;
 #ifdef VR_GEMM_DIAG_BUILD
   const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
@@ -1283,7 +1289,9 @@ __device__ __forceinline__ void direct_epilogue(f32x4 (&acc)[8][4], int row0, in
     }
     // residual rows (and row statistics) of a piece are requested TWO pieces ahead (one piece of arithmetic is ~600 cycles,
     // a global load 1-2 thousand: one ahead left every piece waiting)
-    constexpr int kAhead = 2;
+    // (EPI_RLS_R16_O16 under gemm_f16_pp_kernel comes here for edge tiles only — whole tiles go to rls16_tile_epilogue — and
+    // one piece ahead keeps this path inside the kernel's register budget)
+    constexpr int kAhead = (!FULL && EPI == EPI_RLS_R16_O16) ? 1 : 2;
     float4 r4[kAhead + 1][2] = {};
     float2 st2[kAhead + 1] = {};
     auto fetch_residual = [&](int pc, float4 (&r)[2], float2& st) {
@@ -1447,6 +1455,7 @@ __device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, 
                                                   half_t* xpose) {
   constexpr bool kFold = EPI == EPI_FOLD_F16 || EPI == EPI_FOLD_GELU;
   constexpr bool kGelu = EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU;
+  asm volatile("" : "+v"(lane));  // (the lane-derived offsets below are made per tile, not carried through the K loop)
   const int tok = lane & 15, fg = lane >> 4;
   const float2* lds_stat = reinterpret_cast<const float2*>(tile_const + 768) + trow0;
   const int xw = tok * 32 + ((fg ^ (tok >> 2)) & 3) * 8;  // lane exchange: see direct_epilogue (XPOSE)
@@ -1475,29 +1484,31 @@ __device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int pc = 4 * hb + i;
-        float v[2][4];
+        // pairs of features on the packed-f32 instructions (element for element the operations of direct_epilogue)
+        f32x2 g[4];  // pair 2 q + e: features 4 q + 2 e, + 1 of the lane's eight
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
-          const float gg[4] = {lg4[q].x, lg4[q].y, lg4[q].z, lg4[q].w};
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x = acc[pc][2 * p2 + q][r];
-            v[q][r] = kFold ? fmaf(fmaf(x, unscale, -(stc[i].x * gg[r])), stc[i].y, bb[r]) : x * unscale + bb[r];
+          for (int e = 0; e < 2; ++e) {
+            const f32x2 x = {acc[pc][2 * p2 + q][2 * e], acc[pc][2 * p2 + q][2 * e + 1]};
+            const f32x2 bb = e == 0 ? f32x2{b4[q].x, b4[q].y} : f32x2{b4[q].z, b4[q].w};
+            if (kFold) {
+              const f32x2 gg = e == 0 ? f32x2{lg4[q].x, lg4[q].y} : f32x2{lg4[q].z, lg4[q].w};
+              const f32x2 mean = {stc[i].x, stc[i].x}, inv = {stc[i].y, stc[i].y}, un = {unscale, unscale};
+              g[2 * q + e] = __builtin_elementwise_fma(__builtin_elementwise_fma(x, un, -(mean * gg)), inv, bb);
+            } else {
+              g[2 * q + e] = x * unscale + bb;
+            }
           }
-        }
-        if (kGelu) {
-          f32x2 g[4] = {f32x2{v[0][0], v[0][1]}, f32x2{v[0][2], v[0][3]}, f32x2{v[1][0], v[1][1]}, f32x2{v[1][2], v[1][3]}};
-          gelu_poly2x4(g);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) v[q][0] = g[2 * q].x, v[q][1] = g[2 * q].y, v[q][2] = g[2 * q + 1].x, v[q][3] = g[2 * q + 1].y;
-        }
+        if (kGelu) gelu_poly2x4(g);
         f16x8 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = static_cast<half_t>(fminf(fmaxf(v[0][r], -65504.0f), 65504.0f));
-          h[4 + r] = static_cast<half_t>(fminf(fmaxf(v[1][r], -65504.0f), 65504.0f));
-        }
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            h[4 * q + 2 * e] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].x, -65504.0f), 65504.0f));
+            h[4 * q + 2 * e + 1] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].y, -65504.0f), 65504.0f));
+          }
         *reinterpret_cast<f16x8*>(xpose + i * 512 + xw) = h;
         // (one basic block per piece, as in direct_epilogue: in one long block the SLP vectoriser pairs arithmetic of
         // different pieces and a thousand registers spill)
@@ -1518,6 +1529,155 @@ __device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, 
         out_store(reinterpret_cast<f16x8*>(Ch + (static_cast<int64_t>(row0 + 16 * (4 * hb + i)) * N + col0 + 32 * p2) + xloff), xh[i]);
       asm volatile("" ::: "memory");
     }
+  }
+}
+
+// The sum of one value over the four 16-lane rows of a wave, in every lane: ((r0 + r1) + (r2 + r3)) — the bits of
+// a += __shfl_xor(a, 16); a += __shfl_xor(a, 32) — on v_permlane16_swap / v_permlane32_swap (vector ALU) instead of two
+// ds_bpermute round trips through the LDS queue.
+__device__ __forceinline__ float rows_sum4(float a) {
+  unsigned x = __float_as_uint(a), y = x;
+  asm volatile("" : "+v"(y));  // (two distinct values for the compiler: the swap's two results differ)
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  const unsigned e = r[0], o = r[1];
+  const float s = __uint_as_float(e) + __uint_as_float(o);  // even-row value + odd-row value
+  unsigned u = __float_as_uint(s), w = u;
+  asm volatile("" : "+v"(w));
+  const auto r2 = __builtin_amdgcn_permlane32_swap(u, w, false, false);
+  const unsigned lo = r2[0], hi = r2[1];
+  return __uint_as_float(lo) + __uint_as_float(hi);
+}
+
+// Whole tiles of the two projections that add the residual stream (attention output, FFN-down; EPI_RLS_R16_O16: f16
+// residual rows in, LayerNorm of them applied here, f16 pre-LayerNorm rows and per-row partial statistics out),
+// gemm_f16_pp_kernel only. Same arithmetic per element and the same order of every sum as direct_epilogue (same bits).
+// In the stamps direct_epilogue's predicated path took 25-27k cycles per tile for this variant — as long as the whole K loop
+// of the attention-output projection — for ~6k cycles of arithmetic: sixteen 16-byte loads per wave whose quads address four
+// different rows (64 requests per instruction, like the stores the lane exchange fixed), each waited for with the stores
+// of the piece before it in the same queue, bias / gain / shift / row statistics from global memory, two ds_bpermute
+// round trips per piece for the statistics. Here
+//   * the residual rows arrive by direct-to-LDS loads — no registers, quad-contiguous requests (lane L: token L >> 2, piece
+//     (L & 3) ^ f(token) of the 64-byte half row: the source-side form of the exchange layout), a batch of four pieces
+//     AHEAD of the batch being computed, waited for with a counted vmcnt that leaves the previous batch's stores in flight;
+//   * a piece reads its residual values out of its slot, and writes its f16 result rows into the same slot (LDS executes a
+//     wave's instructions in order); four slots are read back transposed and stored, as in f16_tile_epilogue;
+//   * the tile's constants and row statistics come from the LDS copy the K loop fetched; the sums over the four lane groups
+//     are vector-ALU lane swaps (rows_sum4); the first fragment pair's sums wait in registers the dying accumulators free.
+// xpose: 8 KiB per wave (two batches of four 1-KiB slots) in the stage buffer the K loop has left.
+__device__ __forceinline__ void rls16_tile_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane, const half_t* __restrict__ R16,
+                                                    half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, float unscale,
+                                                    const float* tile_const, int trow0, int tcol0, half_t* xpose) {
+  asm volatile("" : "+v"(lane));
+  const int tok = lane & 15, fg = lane >> 4;
+  const float2* lds_stat = reinterpret_cast<const float2*>(tile_const + 768) + trow0;
+  const int xw = tok * 32 + ((fg ^ (tok >> 2)) & 3) * 8;
+  const int xtr = lane >> 2, xtc = lane & 3;
+  const int xr = xtr * 32 + ((xtc ^ (xtr >> 2)) & 3) * 8;
+  const uint32_t xloff = static_cast<uint32_t>(xtr * N + 8 * xtc);
+  // source of the direct-to-LDS loads: token xtr of the piece, 16-byte piece xtc ^ f(xtr) (it lands at position xtc)
+  const uint32_t rloff = static_cast<uint32_t>(xtr * N + 8 * ((xtc ^ (xtr >> 2)) & 3));
+  auto request = [&](int b) {  // batch b = (p2 = b >> 1, pieces 4 (b & 1) .. + 3) into buffer b & 1
+    half_t* buf = xpose + (b & 1) * 2048;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      glds16(R16 + (static_cast<int64_t>(row0 + 16 * (4 * (b & 1) + i)) * N + col0 + 32 * (b >> 1)) + rloff, buf + i * 512);
+  };
+  float s1[8], s2[8];  // the first fragment pair's sums per piece (this lane's token of it)
+  request(0);
+  float2 st[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * i + tok];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int p2 = b >> 1, hb = b & 1;
+    half_t* buf = xpose + (b & 1) * 2048;
+    asm volatile("" ::: "memory");
+    if (b + 1 < 4) request(b + 1);
+    // younger than this batch's residual rows: the next batch's four loads and the previous batch's stores (four rows,
+    // plus four statistics stores once the second fragment pair is reached)
+    if (b == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (b = 1, 2: 4 stores + 4 loads; b = 3: 4 + 4 stores)
+    float4 b4[2], lg4[2], lb4[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* tc = tile_const + tcol0 + 32 * p2 + 8 * fg + 4 * q;
+      b4[q] = *reinterpret_cast<const float4*>(tc);
+      lg4[q] = *reinterpret_cast<const float4*>(tc + 256);
+      lb4[q] = *reinterpret_cast<const float4*>(tc + 512);
+    }
+    float2 stc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stc[i] = st[i];
+    f16x8 rh4[4];  // the batch's residual values, read together (one exposed LDS round trip per batch, not per piece)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rh4[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xw);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = 4 * hb + i;
+      const f16x8 rh = rh4[i];
+      // pairs of features on the packed-f32 instructions; element for element the operations (and their order) of
+      // direct_epilogue: x = acc * unscale + bias; x += ((r - mean) * inv) * gain + shift
+      // (stage by stage across the four pairs: a dependent chain of packed instructions issues every other slot)
+      f32x2 g[4], t[4];  // pair k = 2 q + e: features 4 q + 2 e, + 1 of the lane's eight
+      const f32x2 mean = {stc[i].x, stc[i].x}, inv = {stc[i].y, stc[i].y};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[k] = f32x2{acc[pc][2 * p2 + (k >> 1)][2 * (k & 1)], acc[pc][2 * p2 + (k >> 1)][2 * (k & 1) + 1]} * unscale;
+        t[k] = f32x2{static_cast<float>(rh[4 * (k >> 1) + 2 * (k & 1)]), static_cast<float>(rh[4 * (k >> 1) + 2 * (k & 1) + 1])} - mean;
+      }
+      auto pair_of = [](const float4& c, int e) { return e == 0 ? f32x2{c.x, c.y} : f32x2{c.z, c.w}; };
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[k] = g[k] + pair_of(b4[k >> 1], k & 1);
+        t[k] = t[k] * inv;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = t[k] * pair_of(lg4[k >> 1], k & 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = t[k] + pair_of(lb4[k >> 1], k & 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = g[k] + t[k];
+      f16x8 h;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          h[4 * q + 2 * e] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].x, -65504.0f), 65504.0f));
+          h[4 * q + 2 * e + 1] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].y, -65504.0f), 65504.0f));
+        }
+      float v[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) v[q][0] = g[2 * q].x, v[q][1] = g[2 * q].y, v[q][2] = g[2 * q + 1].x, v[q][3] = g[2 * q + 1].y;
+      *reinterpret_cast<f16x8*>(buf + i * 512 + xw) = h;  // (behind the read of the same 16 bytes)
+      float a1 = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+      float a2 = ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
+                 ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
+      a1 = rows_sum4(a1);
+      a2 = rows_sum4(a2);
+      if (p2 == 0) {
+        s1[pc] = a1, s2[pc] = a2;
+      } else {
+        a1 += s1[pc];
+        a2 += s2[pc];
+        if (fg == 0)
+          (reinterpret_cast<float2*>(Cl) + (static_cast<int64_t>(row0 + 16 * pc) * (N >> 6) + (col0 >> 6)))[static_cast<uint32_t>(tok * (N >> 6))] =
+              make_float2(a1, a2);
+      }
+      if (M < 0) asm volatile("s_nop 0");  // (one basic block per piece: see direct_epilogue)
+    }
+    asm volatile("" ::: "memory");
+    if (b + 1 < 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * (4 * ((b + 1) & 1) + i) + tok];
+    }
+    f16x8 xh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      out_store(reinterpret_cast<f16x8*>(Ch + (static_cast<int64_t>(row0 + 16 * (4 * hb + i)) * N + col0 + 32 * p2) + xloff), xh[i]);
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -1574,7 +1734,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   float2* wave_stat = reinterpret_cast<float2*>(lds + 2 * kStageHalfs + wave * kWaveStatHalfs);
   // the epilogue's lane exchange (direct_epilogue: xpose) uses stage buffer 1: the K loop ends on it (nk is even), the next
   // tile's K-tile 0 is in buffer 0, and nothing loads into buffer 1 before the barrier that follows the epilogue
-  half_t* xpose = lds + kStageHalfs + wave * 2048;
+  half_t* xpose = lds + kStageHalfs + wave * 4096;  // 8 KiB per wave
   // the tile's epilogue constants (direct_epilogue: tile_const), fetched by waves 0-4 at the start of the tile's K loop —
   // one direct-to-LDS load each — so that the epilogue starts on LDS reads instead of three rounds of global-load latency
   half_t* tile_const_h = lds + 2 * kStageHalfs + 8 * kWaveStatHalfs;
@@ -1586,8 +1746,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   // has left beside its staging state; those keep the predicated form and their global loads)
   constexpr bool kBranchFree = EPI != EPI_BIAS_RESIDUAL_LN && EPI != EPI_BIAS_RESIDUAL_LN_STATS && EPI != EPI_RLS_R32_O16 &&
                                EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
+  constexpr bool kRlsTile = kXposeStores && EPI == EPI_RLS_R16_O16;  // whole tiles: rls16_tile_epilogue
   auto issue_tile_consts = [&](int bm_, int bn_) {
-    if (!kBranchFree || bm_ + GBM > M || bn_ + GBN > N) return;  // edge tiles read them from global memory (predicated epilogue)
+    if (!(kBranchFree || kRlsTile) || bm_ + GBM > M || bn_ + GBN > N) return;  // edge tiles read them from global memory (predicated epilogue)
     // (the lane offset is made opaque per call: left visible, the compiler keeps five per-lane 64-bit source addresses alive
     // across the whole kernel — ten registers the epilogue does not have)
     int l8 = lane * 8;  // 16 bytes per lane, in halfs
@@ -1655,6 +1816,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   const int nk = K / 64;  // even
 #ifdef VR_GEMM_DIAG_BUILD
   const int diag_bits = __builtin_amdgcn_readfirstlane(g_gemm_diag);
+#endif
+#ifdef VR_GEMM_HAS_STAMPS
   const bool stamp_on = static_cast<int>(blockIdx.x) == G / 2;
   int tile_seq = 0;
 #endif
@@ -1695,10 +1858,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   if (wm == 1) VR_PP_BARRIER();  // waves 4-7 run one segment behind from here on
 
   while (true) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int next = tile + G;
     const bool has_next = next < total;
     int nbm = bm, nbn = bn;
@@ -1707,8 +1866,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
 
     // one K-tile out of stage buffer B; the next K-tile (or K-tile 0 of the next tile, or — at the very
     // end — a harmless re-load) goes into buffer B ^ 1
-    auto ktile = [&](auto bsel, int kt) {
+    // FIRST (a tile's K-tile 0): the first MFMA into each accumulator takes a zero C operand instead of the accumulator, so
+    // the accumulators are never cleared (128 v_mov per wave and tile, all eight waves at once, nothing under them)
+    auto ktile = [&](auto bsel, int kt, auto first_sel) {
       constexpr int B = decltype(bsel)::value;
+      constexpr bool FIRST = decltype(first_sel)::value;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       const half_t* st = lds + B * kStageHalfs;
       half_t* nd = lds + (B ^ 1) * kStageHalfs;
       const bool lastk = kt == nk - 1;
@@ -1743,7 +1906,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], (FIRST && kk == 0) ? zero4 : acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 1: rows 0-63 x columns 32-63 ---------------------------------------------------------
@@ -1764,7 +1927,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[i][2 + j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], (FIRST && kk == 0) ? zero4 : acc[i][2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 2: rows 64-127 x columns 32-63 -------------------------------------------------------
@@ -1783,7 +1946,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[4 + i][2 + j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], (FIRST && kk == 0) ? zero4 : acc[4 + i][2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
       // ---- phase 3: rows 64-127 x columns 0-31 (W fragments read again: holding them costs 16 VGPRs) ----
@@ -1805,14 +1968,16 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            if (!VR_DIAG(4)) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], acc[4 + i][j], 0, 0, 0);
+            if (!VR_DIAG(4)) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], af[i][kk], (FIRST && kk == 0) ? zero4 : acc[4 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       VR_PP_BARRIER();
     };
+    ktile(std::integral_constant<int, 0>{}, 0, std::true_type{});
+    ktile(std::integral_constant<int, 1>{}, 1, std::false_type{});
 #pragma clang loop unroll(disable)
-    for (int kt = 0; kt < nk; kt += 2) {
-      ktile(std::integral_constant<int, 0>{}, kt);
-      ktile(std::integral_constant<int, 1>{}, kt + 1);
+    for (int kt = 2; kt < nk; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, kt, std::false_type{});
+      ktile(std::integral_constant<int, 1>{}, kt + 1, std::false_type{});
     }
 
     // waves 0-3 are a segment ahead: they wait here for waves 4-7's last MFMA segment, so that all eight waves
@@ -1832,11 +1997,14 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     if (kTileEpilogue && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
       f16_tile_epilogue<EPI>(acc, bm + wm * 128, bn + wn * 64, lane, Ch, M, N, unscale, reinterpret_cast<const float*>(tile_const_h),
                              wm * 128, wn * 64, xpose);
+    else if (kRlsTile && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
+      rls16_tile_epilogue(acc, bm + wm * 128, bn + wn * 64, lane, reinterpret_cast<const half_t*>(R), Ch, Cl, M, N, unscale,
+                          reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose);
     else if (kBranchFree && whole_tile)
       direct_epilogue<EPI, true, kXposeStores>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
                                  reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose);
     else
-      direct_epilogue<EPI, false, kXposeStores>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
+      direct_epilogue<EPI, false, kXposeStores && !kRlsTile>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
                                   nullptr, 0, 0, xpose);
     } else if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 1.0f) {  // (diagnostic) keep the accumulators alive
       float t = 0.0f;
@@ -1845,7 +2013,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       C[0] = t;
     }
     VR_PP_STAMP(4);
-#ifdef VR_GEMM_DIAG_BUILD
+#ifdef VR_GEMM_HAS_STAMPS
     ++tile_seq;
 #endif
     if (!has_next) break;
@@ -2339,7 +2507,7 @@ static void launch_pp(int epi, int grid, hipStream_t s, const half_t* Ah, const 
     default: VR_LAUNCH_PP(EPI_BIAS_RESIDUAL); break;
   }
 #undef VR_LAUNCH_PP
-#ifdef VR_GEMM_DIAG_BUILD
+#ifdef VR_GEMM_HAS_STAMPS
   static int stamps_left = getenv("VR_GEMM_STAMPS") ? atoi(getenv("VR_GEMM_STAMPS")) : 0;
   if (stamps_left > 0) {
     --stamps_left;
