@@ -1506,8 +1506,8 @@ __device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, 
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            h[4 * q + 2 * e] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].x, -65504.0f), 65504.0f));
-            h[4 * q + 2 * e + 1] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].y, -65504.0f), 65504.0f));
+            h[4 * q + 2 * e] = static_cast<half_t>(g[2 * q + e].x);  // (saturating: MODE.FP16_OVFL, set by the kernel)
+            h[4 * q + 2 * e + 1] = static_cast<half_t>(g[2 * q + e].y);
           }
         *reinterpret_cast<f16x8*>(xpose + i * 512 + xw) = h;
         // (one basic block per piece, as in direct_epilogue: in one long block the SLP vectoriser pairs arithmetic of
@@ -1643,8 +1643,8 @@ __device__ __forceinline__ void rls16_tile_epilogue(f32x4 (&acc)[8][4], int row0
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          h[4 * q + 2 * e] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].x, -65504.0f), 65504.0f));
-          h[4 * q + 2 * e + 1] = static_cast<half_t>(fminf(fmaxf(g[2 * q + e].y, -65504.0f), 65504.0f));
+          h[4 * q + 2 * e] = static_cast<half_t>(g[2 * q + e].x);  // (saturating: MODE.FP16_OVFL, set by the kernel)
+          h[4 * q + 2 * e + 1] = static_cast<half_t>(g[2 * q + e].y);
         }
       float v[2][4];
 #pragma unroll
@@ -1725,6 +1725,10 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   };
   int tile = local;
   if (tile >= total) return;  // block-uniform
+  // MODE.FP16_OVFL: f32 -> f16 conversions saturate at +-65504 instead of overflowing to infinity — for every finite input the
+  // bits of clamp-then-convert (scripts/probe_fp16_ovfl.hip: 100,000 values, none differs; an infinite input stays infinite,
+  // where the clamp makes it 65504), without the v_med3_f32 per element the whole-tile epilogues spent on the clamp
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
   int bm, bn;
   coords(tile, bm, bn);
   const int tid = threadIdx.x;
@@ -1861,7 +1865,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const int next = tile + G;
     const bool has_next = next < total;
     int nbm = bm, nbn = bn;
-    if (has_next) coords(next, nbm, nbn);
     VR_PP_STAMP(0);
 
     // one K-tile out of stage buffer B; the next K-tile (or K-tile 0 of the next tile, or — at the very
@@ -1973,6 +1976,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
       VR_PP_BARRIER();
     };
     ktile(std::integral_constant<int, 0>{}, 0, std::true_type{});
+    // (the next tile's coordinates — three integer divisions — are worked out here, under the K loop, not between the
+    // epilogue and the first K-tile where every wave of the block would wait for them)
+    if (has_next) coords(next, nbm, nbn);
     ktile(std::integral_constant<int, 1>{}, 1, std::false_type{});
 #pragma clang loop unroll(disable)
     for (int kt = 2; kt < nk; kt += 2) {
