@@ -1752,14 +1752,17 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
                                EPI != EPI_RLS_R16_O16 && EPI != EPI_RLS_R16_O32;
   constexpr bool kRlsTile = kXposeStores && EPI == EPI_RLS_R16_O16;  // whole tiles: rls16_tile_epilogue
   auto issue_tile_consts = [&](int bm_, int bn_) {
-    if (!(kBranchFree || kRlsTile) || bm_ + GBM > M || bn_ + GBN > N) return;  // edge tiles read them from global memory (predicated epilogue)
+    // edge tiles read them from global memory (predicated epilogue) — except a last column tile that ends on a 64-column
+    // boundary (N = 384, 1152: the waves behind the edge have nothing to store, the others run the whole-tile epilogue)
+    if (!(kBranchFree || kRlsTile) || bm_ + GBM > M || (bn_ + GBN > N && N % 64 != 0)) return;
     // (the lane offset is made opaque per call: left visible, the compiler keeps five per-lane 64-bit source addresses alive
     // across the whole kernel — ten registers the epilogue does not have)
     int l8 = lane * 8;  // 16 bytes per lane, in halfs
     asm volatile("" : "+v"(l8));
-    if (wave == 0) glds16(reinterpret_cast<const half_t*>(bias + bn_) + l8, tile_const_h);
-    if (wave == 1 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_g + bn_) + l8, tile_const_h + 512);
-    if (wave == 2 && kUsesShift) glds16(reinterpret_cast<const half_t*>(ln_b + bn_) + l8, tile_const_h + 1024);
+    const int c8 = min(2 * bn_ + l8, 2 * N - 8);  // (columns behind the edge re-read the last four: never used)
+    if (wave == 0) glds16(reinterpret_cast<const half_t*>(bias) + c8, tile_const_h);
+    if (wave == 1 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_g) + c8, tile_const_h + 512);
+    if (wave == 2 && kUsesShift) glds16(reinterpret_cast<const half_t*>(ln_b) + c8, tile_const_h + 1024);
     if (wave == 3 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_stat + bm_) + l8, tile_const_h + 1536);
     if (wave == 4 && kUsesGain) glds16(reinterpret_cast<const half_t*>(ln_stat + bm_ + 128) + l8, tile_const_h + 2048);
   };
@@ -1995,12 +1998,16 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     // W hi / A hi of the next tile's K-tile 0 may still be in flight: waited for HERE, before this wave's
     // stores queue up behind them (vmcnt retires in order: a counted wait in the next main loop would otherwise
     // wait for the stores too).
-    const bool whole_tile = bm + GBM <= M && bn + GBN <= N;  // block-uniform
+    // whole tile, or a last column tile that ends on a 64-column boundary: every wave's 64 columns are in or out as a whole
+    const bool whole_tile = bm + GBM <= M && (bn + GBN <= N || N % 64 == 0);  // block-uniform
+    const bool no_columns = bn + wn * 64 >= N;                                // wave-uniform: nothing to store
     counted_tail = kEpiStores > 0 && whole_tile && !VR_DIAG(2) && !VR_DIAG(32);
     if (!counted_tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VR_PP_STAMP(3);
     if (!VR_DIAG(2)) {
-    if (kTileEpilogue && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
+    if (whole_tile && no_columns)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counted waits of the next K loop assume this wave's stores)
+    else if (kTileEpilogue && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
       f16_tile_epilogue<EPI>(acc, bm + wm * 128, bn + wn * 64, lane, Ch, M, N, unscale, reinterpret_cast<const float*>(tile_const_h),
                              wm * 128, wn * 64, xpose);
     else if (kRlsTile && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
@@ -2439,8 +2446,10 @@ static bool pp_usable(int N, int K) {
 // kernel's 930 — its epilogues do overlap the other block's main loop, but 32-deep stages of a 256x128 tile pull
 // 1.5x the bytes through L2 -> LDS in 64-byte row segments, and that path (14.5 TB/s here) is what bounds it.
 static bool d2_usable(int N, int K) {
-  static const bool d2_on = getenv("VR_GEMM_D2") && atoi(getenv("VR_GEMM_D2")) == 1;
-  return d2_on && K % D2K == 0 && N % 8 == 0;
+  // VR_GEMM_D2=1: every projection; 2: only those whose width leaves the 256-wide kernel half a column tile (N % 256 != 0)
+  static const int d2_mode = getenv("VR_GEMM_D2") ? atoi(getenv("VR_GEMM_D2")) : 0;
+  const bool on = d2_mode == 1 || (d2_mode == 2 && N % 256 != 0);
+  return on && K % D2K == 0 && N % 8 == 0;
 }
 
 // the kernels whose epilogue is direct_epilogue (all EPI_* variants, f16 residual stream included)
@@ -3562,7 +3571,12 @@ static int forward_chunk(vr_engine* e, Encoder* enc, const int32_t* ids_dev, con
         lds_allowed[which] = lds_bytes;
       }
       const dim3 sgrid(static_cast<unsigned>(n_seq) * static_cast<unsigned>(nh));
+#ifdef VR_GEMM_DIAG_BUILD  // (timing experiment: VR_ATTN_QLIMIT=16 leaves the staging and one query tile per block)
+      static const int q_limit_env = getenv("VR_ATTN_QLIMIT") ? atoi(getenv("VR_ATTN_QLIMIT")) : 0;
+      const int q_limit = tail ? 16 : (q_limit_env > 0 ? q_limit_env : max_len);
+#else
       const int q_limit = tail ? 16 : max_len;
+#endif
       static const int attn_waves = getenv("VR_ATTN_WAVES") ? atoi(getenv("VR_ATTN_WAVES")) : 4;  // (experiment switch: 4 or 8)
 #define VR_ATTN_SEQ(DHV, NWV)                                                                                                   \
   hipLaunchKernelGGL((attention_seq_kernel<DHV, NWV>), sgrid, dim3(NWV * 64), lds_bytes, s, reinterpret_cast<const half_t*>(enc->qkv), \
