@@ -1532,20 +1532,21 @@ __device__ __forceinline__ void f16_tile_epilogue(f32x4 (&acc)[8][4], int row0, 
   }
 }
 
-// The sum of one value over the four 16-lane rows of a wave, in every lane: ((r0 + r1) + (r2 + r3)) — the bits of
-// a += __shfl_xor(a, 16); a += __shfl_xor(a, 32) — on v_permlane16_swap / v_permlane32_swap (vector ALU) instead of two
-// ds_bpermute round trips through the LDS queue.
-__device__ __forceinline__ float rows_sum4(float a) {
-  unsigned x = __float_as_uint(a), y = x;
-  asm volatile("" : "+v"(y));  // (two distinct values for the compiler: the swap's two results differ)
-  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
-  const unsigned e = r[0], o = r[1];
-  const float s = __uint_as_float(e) + __uint_as_float(o);  // even-row value + odd-row value
-  unsigned u = __float_as_uint(s), w = u;
-  asm volatile("" : "+v"(w));
-  const auto r2 = __builtin_amdgcn_permlane32_swap(u, w, false, false);
-  const unsigned lo = r2[0], hi = r2[1];
-  return __uint_as_float(lo) + __uint_as_float(hi);
+// Four values summed over the four 16-lane rows of a wave at once: afterwards the lanes of row r hold the total of value r,
+// ((r0 + r1) + (r2 + r3)) — the bits of a += __shfl_xor(a, 16); a += __shfl_xor(a, 32) — in three lane swaps and three adds
+// (v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second, v_permlane32_swap the
+// upper half of the first with the lower half of the second: each swap + add halves two values at a time), on the vector
+// ALU instead of eight ds_bpermute round trips through the LDS queue.
+__device__ __forceinline__ float rows_sum4x4(float v0, float v1, float v2, float v3) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const float s01 = __uint_as_float(a0) + __uint_as_float(a1);  // rows: v0 (r0 + r1), v1 (r0 + r1), v0 (r2 + r3), v1 (r2 + r3)
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  const float s23 = __uint_as_float(b0) + __uint_as_float(b1);
+  const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+  const unsigned c0 = c[0], c1 = c[1];
+  return __uint_as_float(c0) + __uint_as_float(c1);  // row r: value r, (r0 + r1) + (r2 + r3)
 }
 
 // Whole tiles of the two projections that add the residual stream (attention output, FFN-down; EPI_RLS_R16_O16: f16
@@ -1566,7 +1567,7 @@ __device__ __forceinline__ float rows_sum4(float a) {
 // xpose: 8 KiB per wave (two batches of four 1-KiB slots) in the stage buffer the K loop has left.
 __device__ __forceinline__ void rls16_tile_epilogue(f32x4 (&acc)[8][4], int row0, int col0, int lane, const half_t* __restrict__ R16,
                                                     half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M, int N, float unscale,
-                                                    const float* tile_const, int trow0, int tcol0, half_t* xpose) {
+                                                    const float* tile_const, int trow0, int tcol0, half_t* xpose, half_t* xspare) {
   asm volatile("" : "+v"(lane));
   const int tok = lane & 15, fg = lane >> 4;
   const float2* lds_stat = reinterpret_cast<const float2*>(tile_const + 768) + trow0;
@@ -1576,60 +1577,74 @@ __device__ __forceinline__ void rls16_tile_epilogue(f32x4 (&acc)[8][4], int row0
   const uint32_t xloff = static_cast<uint32_t>(xtr * N + 8 * xtc);
   // source of the direct-to-LDS loads: token xtr of the piece, 16-byte piece xtc ^ f(xtr) (it lands at position xtc)
   const uint32_t rloff = static_cast<uint32_t>(xtr * N + 8 * ((xtc ^ (xtr >> 2)) & 3));
-  auto request = [&](int b) {  // batch b = (p2 = b >> 1, pieces 4 (b & 1) .. + 3) into buffer b & 1
-    half_t* buf = xpose + (b & 1) * 2048;
+  // Groups of two pieces, g = 0..7: fragment pair p2 = g >> 2, pieces 2 (g & 3), + 1. Five slot pairs (four in the stage
+  // buffer the K loop has left, one in the LDS behind the tile constants) carry the group being computed and the four
+  // behind it: a group's residual rows are requested FOUR groups (eight pieces of arithmetic) before they are read — with
+  // batches of four pieces and one batch of lead every batch waited for memory (stamps: 17-19k cycles per tile against 9k of
+  // vector instructions).
+  auto pair_of_group = [&](int g) { return (g % 5) < 4 ? xpose + (g % 5) * 1024 : xspare; };
+  auto request = [&](int g) {
+    half_t* buf = pair_of_group(g);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16(R16 + (static_cast<int64_t>(row0 + 16 * (4 * (b & 1) + i)) * N + col0 + 32 * (b >> 1)) + rloff, buf + i * 512);
+    for (int i = 0; i < 2; ++i)
+      glds16(R16 + (static_cast<int64_t>(row0 + 16 * (2 * (g & 3) + i)) * N + col0 + 32 * (g >> 2)) + rloff, buf + i * 512);
   };
-  float s1[8], s2[8];  // the first fragment pair's sums per piece (this lane's token of it)
-  request(0);
-  float2 st[4];
+  float sk[4];  // the first fragment pair's sums, one register per group: lane row fg holds (a1, a2) of the group's first piece (fg = 0, 1) and of its second (fg = 2, 3)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * i + tok];
+  for (int g = 0; g < 5; ++g) request(g);
+  float4 b4[2], lg4[2], lb4[2];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int p2 = b >> 1, hb = b & 1;
-    half_t* buf = xpose + (b & 1) * 2048;
+  for (int g = 0; g < 8; ++g) {
+    const int p2 = g >> 2;
+    half_t* buf = pair_of_group(g);
     asm volatile("" ::: "memory");
-    if (b + 1 < 4) request(b + 1);
-    // younger than this batch's residual rows: the next batch's four loads and the previous batch's stores (four rows,
-    // plus four statistics stores once the second fragment pair is reached)
-    if (b == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (b = 1, 2: 4 stores + 4 loads; b = 3: 4 + 4 stores)
-    float4 b4[2], lg4[2], lb4[2];
+    // operations younger than this group's two loads (the loads of the groups behind it, the stores of the groups before
+    // it): what the counted wait leaves in flight
+    // (a group of the first fragment pair issues two stores, one of the second three — its statistics; groups 0-2 are followed
+    // by the two loads of the group five behind)
+    if (g == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // D1-D4
+    else if (g == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // D2-D4, S0, D5
+    else if (g == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // D3, D4, S0, D5, S1, D6
+    else if (g <= 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // g = 3: D4, (S, D) x 3; g = 4: (S, D) x 3, S3
+    else if (g == 5) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // S1, D6, S2, D7, S3, S4 (3)
+    else if (g == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // S2, D7, S3, S4 (3), S5 (3)
+    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");              // S3, S4, S5, S6 (3 each but S3)
+    if ((g & 3) == 0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float* tc = tile_const + tcol0 + 32 * p2 + 8 * fg + 4 * q;
-      b4[q] = *reinterpret_cast<const float4*>(tc);
-      lg4[q] = *reinterpret_cast<const float4*>(tc + 256);
-      lb4[q] = *reinterpret_cast<const float4*>(tc + 512);
+      for (int q = 0; q < 2; ++q) {
+        const float* tc = tile_const + tcol0 + 32 * p2 + 8 * fg + 4 * q;
+        b4[q] = *reinterpret_cast<const float4*>(tc);
+        lg4[q] = *reinterpret_cast<const float4*>(tc + 256);
+        lb4[q] = *reinterpret_cast<const float4*>(tc + 512);
+      }
     }
-    float2 stc[4];
+    float2 stc[2];
+    f16x8 rh2[2];  // the group's residual values and row statistics, read together
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stc[i] = st[i];
-    f16x8 rh4[4];  // the batch's residual values, read together (one exposed LDS round trip per batch, not per piece)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rh4[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xw);
+    for (int i = 0; i < 2; ++i) {
+      stc[i] = lds_stat[16 * (2 * (g & 3) + i) + tok];
+      rh2[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xw);
+    }
     asm volatile("" ::: "memory");
+    float pa1[2], pa2[2];  // the two pieces' sums over this lane's eight features
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pc = 4 * hb + i;
-      const f16x8 rh = rh4[i];
+    for (int i = 0; i < 2; ++i) {
+      const int pc = 2 * (g & 3) + i;
+      const f16x8 rh = rh2[i];
       // pairs of features on the packed-f32 instructions; element for element the operations (and their order) of
       // direct_epilogue: x = acc * unscale + bias; x += ((r - mean) * inv) * gain + shift
       // (stage by stage across the four pairs: a dependent chain of packed instructions issues every other slot)
-      f32x2 g[4], t[4];  // pair k = 2 q + e: features 4 q + 2 e, + 1 of the lane's eight
+      f32x2 g2[4], t[4];  // pair k = 2 q + e: features 4 q + 2 e, + 1 of the lane's eight
       const f32x2 mean = {stc[i].x, stc[i].x}, inv = {stc[i].y, stc[i].y};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        g[k] = f32x2{acc[pc][2 * p2 + (k >> 1)][2 * (k & 1)], acc[pc][2 * p2 + (k >> 1)][2 * (k & 1) + 1]} * unscale;
+        g2[k] = f32x2{acc[pc][2 * p2 + (k >> 1)][2 * (k & 1)], acc[pc][2 * p2 + (k >> 1)][2 * (k & 1) + 1]} * unscale;
         t[k] = f32x2{static_cast<float>(rh[4 * (k >> 1) + 2 * (k & 1)]), static_cast<float>(rh[4 * (k >> 1) + 2 * (k & 1) + 1])} - mean;
       }
       auto pair_of = [](const float4& c, int e) { return e == 0 ? f32x2{c.x, c.y} : f32x2{c.z, c.w}; };
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        g[k] = g[k] + pair_of(b4[k >> 1], k & 1);
+        g2[k] = g2[k] + pair_of(b4[k >> 1], k & 1);
         t[k] = t[k] * inv;
       }
 #pragma unroll
@@ -1637,47 +1652,45 @@ __device__ __forceinline__ void rls16_tile_epilogue(f32x4 (&acc)[8][4], int row0
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = t[k] + pair_of(lb4[k >> 1], k & 1);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = g[k] + t[k];
+      for (int k = 0; k < 4; ++k) g2[k] = g2[k] + t[k];
       f16x8 h;
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          h[4 * q + 2 * e] = static_cast<half_t>(g[2 * q + e].x);  // (saturating: MODE.FP16_OVFL, set by the kernel)
-          h[4 * q + 2 * e + 1] = static_cast<half_t>(g[2 * q + e].y);
+          h[4 * q + 2 * e] = static_cast<half_t>(g2[2 * q + e].x);  // (saturating: MODE.FP16_OVFL, set by the kernel)
+          h[4 * q + 2 * e + 1] = static_cast<half_t>(g2[2 * q + e].y);
         }
       float v[2][4];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) v[q][0] = g[2 * q].x, v[q][1] = g[2 * q].y, v[q][2] = g[2 * q + 1].x, v[q][3] = g[2 * q + 1].y;
+      for (int q = 0; q < 2; ++q) v[q][0] = g2[2 * q].x, v[q][1] = g2[2 * q].y, v[q][2] = g2[2 * q + 1].x, v[q][3] = g2[2 * q + 1].y;
       *reinterpret_cast<f16x8*>(buf + i * 512 + xw) = h;  // (behind the read of the same 16 bytes)
-      float a1 = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-      float a2 = ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
-                 ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
-      a1 = rows_sum4(a1);
-      a2 = rows_sum4(a2);
-      if (p2 == 0) {
-        s1[pc] = a1, s2[pc] = a2;
-      } else {
-        a1 += s1[pc];
-        a2 += s2[pc];
-        if (fg == 0)
-          (reinterpret_cast<float2*>(Cl) + (static_cast<int64_t>(row0 + 16 * pc) * (N >> 6) + (col0 >> 6)))[static_cast<uint32_t>(tok * (N >> 6))] =
-              make_float2(a1, a2);
-      }
+      pa1[i] = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+      pa2[i] = ((v[0][0] * v[0][0] + v[0][1] * v[0][1]) + (v[0][2] * v[0][2] + v[0][3] * v[0][3])) +
+               ((v[1][0] * v[1][0] + v[1][1] * v[1][1]) + (v[1][2] * v[1][2] + v[1][3] * v[1][3]));
       if (M < 0) asm volatile("s_nop 0");  // (one basic block per piece: see direct_epilogue)
     }
-    asm volatile("" ::: "memory");
-    if (b + 1 < 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) st[i] = lds_stat[16 * (4 * ((b + 1) & 1) + i) + tok];
+    {
+      // sums over the four lane groups, the group's four values at once: lane row 0 / 1 ends up with (sum, sum of squares)
+      // of the first piece's token `tok`, row 2 / 3 with the second piece's
+      float tot = rows_sum4x4(pa1[0], pa2[0], pa1[1], pa2[1]);
+      if (p2 == 0) {
+        sk[g & 3] = tot;
+      } else {
+        tot += sk[g & 3];
+        const int pc = 2 * (g & 3) + (fg >> 1);
+        (reinterpret_cast<float*>(Cl) + 2 * (static_cast<int64_t>(row0 + 16 * pc) * (N >> 6) + (col0 >> 6)))[static_cast<uint32_t>(2 * tok * (N >> 6) + (fg & 1))] = tot;
+      }
     }
-    f16x8 xh[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xh[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xr);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      out_store(reinterpret_cast<f16x8*>(Ch + (static_cast<int64_t>(row0 + 16 * (4 * hb + i)) * N + col0 + 32 * p2) + xloff), xh[i]);
     asm volatile("" ::: "memory");
+    f16x8 xh[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xh[i] = *reinterpret_cast<const f16x8*>(buf + i * 512 + xr);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      out_store(reinterpret_cast<f16x8*>(Ch + (static_cast<int64_t>(row0 + 16 * (2 * (g & 3) + i)) * N + col0 + 32 * p2) + xloff), xh[i]);
+    asm volatile("" ::: "memory");
+    if (g + 5 < 8) request(g + 5);  // (into the slot pair this group has just read back)
   }
 }
 
@@ -1708,7 +1721,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
     const float* __restrict__ R, float* __restrict__ C, half_t* __restrict__ Ch, half_t* __restrict__ Cl, int M,
     int N, int K, float unscale, const float2* __restrict__ ln_stat, const float* __restrict__ ln_g,
     const float* __restrict__ ln_b, int stagger_sleeps, int group_m) {
-  __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs + kTileConstHalfs];  // the only LDS object (see gemm_f16x3_256_kernel)
+  __shared__ half_t lds[2 * kStageHalfs + 8 * kWaveStatHalfs + kTileConstHalfs + 8 * 1024];  // the only LDS object (see gemm_f16x3_256_kernel)
   const int tiles_n = (N + GBN - 1) / GBN;
   const int tiles_m = (M + GBM - 1) / GBM;
   const int total = tiles_m * tiles_n;
@@ -1739,6 +1752,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
   // the epilogue's lane exchange (direct_epilogue: xpose) uses stage buffer 1: the K loop ends on it (nk is even), the next
   // tile's K-tile 0 is in buffer 0, and nothing loads into buffer 1 before the barrier that follows the epilogue
   half_t* xpose = lds + kStageHalfs + wave * 4096;  // 8 KiB per wave
+  half_t* xspare = lds + 2 * kStageHalfs + 8 * kWaveStatHalfs + kTileConstHalfs + wave * 1024;  // + 2 KiB per wave (rls16_tile_epilogue)
   // the tile's epilogue constants (direct_epilogue: tile_const), fetched by waves 0-4 at the start of the tile's K loop —
   // one direct-to-LDS load each — so that the epilogue starts on LDS reads instead of three rounds of global-load latency
   half_t* tile_const_h = lds + 2 * kStageHalfs + 8 * kWaveStatHalfs;
@@ -2012,7 +2026,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(
                              wm * 128, wn * 64, xpose);
     else if (kRlsTile && whole_tile && !VR_DIAG(32) && !VR_DIAG(64))
       rls16_tile_epilogue(acc, bm + wm * 128, bn + wn * 64, lane, reinterpret_cast<const half_t*>(R), Ch, Cl, M, N, unscale,
-                          reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose);
+                          reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose, xspare);
     else if (kBranchFree && whole_tile)
       direct_epilogue<EPI, true, kXposeStores>(acc, bm + wm * 128, bn + wn * 64, lane, bias, R, C, Ch, Cl, M, N, unscale, ln_stat, ln_g, ln_b, wave_stat,
                                  reinterpret_cast<const float*>(tile_const_h), wm * 128, wn * 64, xpose);
