@@ -204,6 +204,7 @@ static void lane_view(vr_engine* L, const vr_engine* m) {
   L->centre = m->centre;
   L->centre_norm = m->centre_norm;
   L->centre_rows = m->centre_rows;
+  L->centre_checked_rows = m->centre_checked_rows;
   L->live = m->live;
   L->folder = m->folder;
   L->index_folder = m->index_folder;
@@ -487,11 +488,15 @@ static int upsert_locked(vr_engine* e, int64_t n, int mem, const float* dense, c
   // shadow of the rows just stored (no-op without prefilter); the int8 shadow is re-centred — all of it rebuilt —
   // whenever the collection has doubled since its centre was last computed
   e->n_rows = first + n;  // (prefilter_recentre works on [0, n_rows); the count is set again below)
-  if (e->prefilter8 && first + n >= 1024 && first + n >= 2 * e->centre_rows)
-    VR_TRY(prefilter_recentre(e));
-  else
-    VR_TRY(prefilter_store_rows(e, n, first));
-  e->n_rows = first;
+  {
+    // re-centre when the collection has doubled since a re-centring was last attempted (centre_checked_rows, not centre_rows:
+    // with centring switched off or a non-finite centre the latter stays 0 and every upsert would rebuild the whole shadow)
+    const int rc = (e->prefilter8 && first + n >= 1024 && first + n >= 2 * std::max(e->centre_rows, e->centre_checked_rows))
+                       ? prefilter_recentre(e)
+                       : prefilter_store_rows(e, n, first);
+    e->n_rows = first;  // (also on failure: rows whose payload columns were never written must not become visible)
+    if (rc != 0) return rc;
+  }
 
   // payload columns are always host arrays (they come from Python metadata)
   if (folder_id) {

@@ -123,8 +123,19 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
   t.prefilter = e->prefilter;
   t.prefilter8 = e->prefilter8;
   t.stream = s;  // (the master's stream: searches run on their lanes' streams)
+  // temporaries of the rebuild (released by fail() on every path out)
+  DevArray<int32_t> map, cnt, tmp_idx;
+  DevArray<float> tmp_val;
+  DevArray<int64_t> begin;
+  DevArray<uint8_t> has_sparse;
   auto fail = [&](int rc) {
     (void)hipStreamSynchronize(s);
+    map.release();
+    cnt.release();
+    tmp_idx.release();
+    tmp_val.release();
+    begin.release();
+    has_sparse.release();
     t.corpus.release();
     t.corpus16.release();
     t.row_err.release();
@@ -150,17 +161,22 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     const int rc_ = (expr);            \
     if (rc_ != 0) return fail(rc_);    \
   } while (0)
+  // HIP calls behind this point fail through fail() as well: a plain VR_HIP return would leak the shadow — a full-size copy
+  // of the index (and the temporaries below, which own their memory and are released by their destructors or here)
+#define VR_CHIP(call)                                                                                       \
+  do {                                                                                                      \
+    hipError_t err_ = (call);                                                                               \
+    if (err_ != hipSuccess) {                                                                               \
+      ::vr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(err_), __FILE__, __LINE__);         \
+      return fail(-1);                                                                                      \
+    }                                                                                                       \
+  } while (0)
   VR_CTRY(ensure_rows(&t, std::max<int64_t>(e->cap_rows, 1024)));  // same capacity: later appends find the room they had
 
-  DevArray<int32_t> map;
   VR_CTRY(map.grow(std::max<int64_t>(n_new, 1), 0, s));
-  if (n_new) VR_HIP(hipMemcpyAsync(map.p, old_of_new.data(), sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyHostToDevice, s));
+  if (n_new) VR_CHIP(hipMemcpyAsync(map.p, old_of_new.data(), sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyHostToDevice, s));
 
   // ---- sparse rows out of the old slices, into a temporary CSR
-  DevArray<int32_t> cnt, tmp_idx;
-  DevArray<float> tmp_val;
-  DevArray<int64_t> begin;
-  DevArray<uint8_t> has_sparse;
   std::vector<int32_t> cnt_host(static_cast<size_t>(n_new));
   std::vector<int64_t> begin_host(static_cast<size_t>(n_new) + 1, 0);
   const bool any_sparse = !e->slices_host.empty() && n_new > 0;
@@ -169,15 +185,15 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     VR_CTRY(cnt.grow(n_new, 0, s));
     hipLaunchKernelGGL(count_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
                        e->sp_idx.p, cnt.p);
-    VR_HIP(hipMemcpyAsync(cnt_host.data(), cnt.p, sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyDeviceToHost, s));
-    VR_HIP(hipStreamSynchronize(s));
+    VR_CHIP(hipMemcpyAsync(cnt_host.data(), cnt.p, sizeof(int32_t) * static_cast<size_t>(n_new), hipMemcpyDeviceToHost, s));
+    VR_CHIP(hipStreamSynchronize(s));
     for (int64_t i = 0; i < n_new; ++i) begin_host[static_cast<size_t>(i) + 1] = begin_host[static_cast<size_t>(i)] + cnt_host[static_cast<size_t>(i)];
     const int64_t nnz = begin_host.back();
     VR_CTRY(begin.grow(n_new + 1, 0, s));
     VR_CTRY(tmp_idx.grow(std::max<int64_t>(nnz, 1), 0, s));
     VR_CTRY(tmp_val.grow(std::max<int64_t>(nnz, 1), 0, s));
     VR_CTRY(has_sparse.grow(n_new, 0, s));
-    VR_HIP(hipMemcpyAsync(begin.p, begin_host.data(), sizeof(int64_t) * (static_cast<size_t>(n_new) + 1), hipMemcpyHostToDevice, s));
+    VR_CHIP(hipMemcpyAsync(begin.p, begin_host.data(), sizeof(int64_t) * (static_cast<size_t>(n_new) + 1), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(extract_entries_kernel, dim3(blocks), dim3(256), 0, s, map.p, n_new, e->row_slice.p, e->slices.p,
                        e->sp_idx.p, e->sp_val.p, begin.p, tmp_idx.p, tmp_val.p, has_sparse.p);
   }
@@ -190,8 +206,8 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
   VR_CTRY(gather_column(s, e->index_folder, t.index_folder, map.p, n_new));
   VR_CTRY(gather_column(s, e->created, t.created, map.p, n_new));
   VR_CTRY(gather_column(s, e->modified, t.modified, map.p, n_new));
-  VR_HIP(hipMemsetAsync(t.live.p, 1, static_cast<size_t>(n_new), s));  // (ensure_rows zeroed the rest)
-  VR_HIP(hipMemsetAsync(t.row_slice.p, 0xFF, sizeof(int32_t) * static_cast<size_t>(t.cap_rows), s));  // -1
+  VR_CHIP(hipMemsetAsync(t.live.p, 1, static_cast<size_t>(n_new), s));  // (ensure_rows zeroed the rest)
+  VR_CHIP(hipMemsetAsync(t.row_slice.p, 0xFF, sizeof(int32_t) * static_cast<size_t>(t.cap_rows), s));  // -1
 
   // ---- sparse index re-packed in the new row order; the df table and the point count carry over as they are
   t.n_rows = n_new;
@@ -202,9 +218,10 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
                        has_sparse.p, n_new, t.row_slice.p);
   }
   VR_CTRY(prefilter_recentre(&t));  // the shadow of the compacted rows, around THEIR column mean
-  VR_HIP(hipStreamSynchronize(s));
-  VR_HIP(hipGetLastError());
+  VR_CHIP(hipStreamSynchronize(s));
+  VR_CHIP(hipGetLastError());
 #undef VR_CTRY
+#undef VR_CHIP
 
   {  // ---- the swap: the only moment searches wait for
     PublishLock publish(e);
@@ -215,6 +232,7 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     std::swap(e->centre, t.centre);
     std::swap(e->centre_norm, t.centre_norm);
     std::swap(e->centre_rows, t.centre_rows);
+    std::swap(e->centre_checked_rows, t.centre_checked_rows);
     std::swap(e->live, t.live);
     std::swap(e->folder, t.folder);
     std::swap(e->index_folder, t.index_folder);
@@ -239,13 +257,7 @@ int engine_compact(vr_engine* e, int64_t* new_row_of_old, int64_t* n_rows_after)
     e->n_live = n_new;
     e->generation.fetch_add(1);
   }
-  fail(0);  // what the shadow holds now is the old index: release it (no search can still be reading it)
-  map.release();
-  cnt.release();
-  tmp_idx.release();
-  tmp_val.release();
-  begin.release();
-  has_sparse.release();
+  fail(0);  // what the shadow holds now is the old index: release it and the temporaries (no search can still be reading it)
   return 0;
 }
 

@@ -192,6 +192,8 @@ struct vr_engine {
   vr::DevArray<float> centre_sum;  // [dim] scratch of the column sums
   float centre_norm = 0.0f;        // |centre|_2, rounded up
   int64_t centre_rows = 0;         // rows the collection held when the centre was last recomputed
+  int64_t centre_checked_rows = 0; // rows it held when a re-centring was last ATTEMPTED (centring switched off, or a non-finite
+                                   // centre, leaves centre_rows at 0: without this every upsert would rebuild the whole shadow)
   // (a lane counts for itself; its counts are added to the master's when it is handed back)
   std::atomic<int64_t> stat_two_stage{0};       // single-query dense searches served by the two-stage path
   std::atomic<int64_t> stat_fallback{0};        // ... of which overflowed the re-score budget and were redone one-stage

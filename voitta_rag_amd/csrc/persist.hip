@@ -251,6 +251,7 @@ int engine_load(vr_engine* e, const char* path) {
   e->max_folder_id = h.max_folder_id;
   e->max_index_folder_id = h.max_index_folder_id;
   e->centre_rows = 0;
+  e->centre_checked_rows = 0;
   VR_TRY(prefilter_recentre(e));  // derived data (shadow and its centre): rebuilt, not stored
   VR_TRY(inv_rebuild(e));         // likewise the inverted twin of the sparse slices
   VR_HIP(hipStreamSynchronize(e->stream));

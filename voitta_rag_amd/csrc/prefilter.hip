@@ -177,6 +177,7 @@ int prefilter_recentre(vr_engine* e) {
   if (!e->prefilter || !e->prefilter8 || e->n_rows <= 0) return 0;
   const bool centring = !(getenv("VR_PREFILTER_CENTRE") && atoi(getenv("VR_PREFILTER_CENTRE")) == 0);  // (read per call: rare)
   if (!centring) e->centre_rows = 0;
+  e->centre_checked_rows = e->n_rows;
   if (centring && e->n_rows >= kCentreMinRows) {
     static_assert(kTileK == 16, "column_sum_kernel decodes the [k/16][lane][4] image");
     VR_TRY(e->centre.grow(e->dim, 0, e->stream));
