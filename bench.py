@@ -301,6 +301,24 @@ def dropin_section(args, engine, state, rng):
         if i >= 20:
             lat[i - 20] = time.perf_counter() - t1
         assert len(got) == 10
+    if os.environ.get("VR_BENCH_TEXT_DEBUG"):  # where a question's time goes in THIS process state (stderr; not part of the line)
+        tok = emb.model.tokenizer._h
+        l2 = []
+        for q in questions[20:120]:
+            t1 = time.perf_counter()
+            engine.query_text(tok, q, q, 512, 10, 0.1)
+            l2.append(time.perf_counter() - t1)
+        ids, off = emb.model.tokenize([questions[50]])
+        import torch as _t
+        out = _t.empty((1, engine.dim), device=ids.device)
+        l3 = []
+        for _ in range(100):
+            t1 = time.perf_counter()
+            enc.encode(engine, ids, off, out)
+            engine.sync()
+            l3.append(time.perf_counter() - t1)
+        print(f"[text debug] from text p50 {np.percentile(lat, 50) * 1e3:.4f} ms; engine.query_text alone {np.percentile(l2, 50) * 1e3:.4f}; "
+              f"encode alone {np.percentile(l3, 50) * 1e3:.4f}; rows {engine.count()}", file=sys.stderr)
     store_registry.set_engine(None)  # (the engine stays ours to close)
     return (n_chunks / dt, n_chunks, args.dropin_files, float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3),
             sync_rate, n_sync)

@@ -372,7 +372,8 @@ int inv_append(vr_engine* e, int64_t slice0, int64_t n_new, int64_t first_row, i
   // Many small upserts leave many small segments, and a query pays a chain of dependent loads per segment: once
   // there are four times as many as rows / 4096 needs, sort the whole collection into full segments again (the
   // interval between two such rebuilds grows with the collection, like the re-centring of the int8 shadow).
-  if (!rebuilding && e->n_inv_seg > 64 && e->n_inv_seg > 4 * ((e->inv_rows + kInvSegRows - 1) / kInvSegRows))
+  static const int64_t rebuild_factor = getenv("VR_INV_REBUILD_FACTOR") ? std::max(2, atoi(getenv("VR_INV_REBUILD_FACTOR"))) : 4;
+  if (!rebuilding && e->n_inv_seg > 64 && e->n_inv_seg > rebuild_factor * ((e->inv_rows + kInvSegRows - 1) / kInvSegRows))
     return inv_rebuild(e);
   return 0;
 }
