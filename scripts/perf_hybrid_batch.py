@@ -15,6 +15,7 @@ from voitta_rag_amd.engine import fuse_batch  # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+sparse_only = len(sys.argv) > 4 and sys.argv[4] == "sparse_only"   # (timing experiments on the sparse batch kernels)
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev).manual_seed(1234)
 dim = 768
@@ -43,7 +44,7 @@ def timed(name, fn, n=reps):
     return out
 
 
-for kk in (10, 30):
+for kk in (() if sparse_only else (10, 30)):
     s0 = e.stats()
     timed(f"dense batch k={kk} (raw arrays)", lambda: e.search_dense(qs, kk, raw=True))
     s1 = e.stats()
@@ -54,6 +55,14 @@ sp = timed("sparse batch k=30", lambda: e.search_sparse_batch(sq, 30))
 ms, n, _ = e.profile_read(Engine.PROF_SPARSE_SCAN)
 print(f"  sparse_inv_batch_kernel: {ms / max(n, 1):.3f} ms per launch ({n} launches)")
 e.profile(False)
+if sparse_only:
+    st = e.stats()
+    e.search_sparse_batch(sq[:16], 30)  # (the candidate count of a batch is read when the next one starts)
+    st = e.stats()
+    print(f"  grouped queries {st.get('sparse_grouped')}, batches redone {st.get('sparse_group_redo')}, "
+          f"candidates ranked {st.get('sparse_group_candidates')}")
+    e.close()
+    sys.exit(0)
 timed("hybrid batch limit=10", lambda: e.search_hybrid_batch(qs, sq, 10, 0.1, raw=True))
 timed("hybrid batch limit=10 (CSR in, raw out)", lambda: e.search_hybrid_batch(qs, sq_csr, 10, 0.1, raw=True))
 keys = timed("hybrid keys k=30", lambda: e.search_hybrid_keys(qs, sq, 30))

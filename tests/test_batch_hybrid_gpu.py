@@ -108,6 +108,59 @@ def test_sparse_batch_pruning_keeps_the_exact_answer(small, monkeypatch):
                     assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), (blocks, k, i)
 
 
+def test_grouped_sparse_batch_keeps_the_exact_answer(small, monkeypatch):
+    """Batches of 16 queries or more take the GROUPED scan (csrc/invert.hip, sparse_inv_group_kernel): groups of up to 8
+    queries share a block per segment, a term's postings are read once per group and added to every member's
+    accumulators — in ascending term order per query, so the bits stay the forward scan's. Queries from a Zipfian
+    vocabulary (shared common terms, the case it is built for), groups of 8 and of 4, a filter, k from 1 to 64; held
+    against the oracle and against the per-query kernels (VR_SPARSE_GROUPED=0). A candidate buffer too small for a
+    query (VR_SPARSE_GROUP_CAP) makes the engine redo the batch on the per-query kernels: same answer, counted."""
+    from voitta_rag_amd import SearchFilter
+
+    e, rng, x, sp, folder, live, vocab = small
+    df = sp.df
+    by_df = np.array(sorted(df, key=lambda t: -df[t]), np.int32)
+    p = 1.0 / np.arange(1, len(by_df) + 1) ** 1.1
+    p /= p.sum()
+    qs = []
+    for i in range(130):
+        m = int(rng.integers(1, 9))
+        ids = rng.choice(by_df, size=m, replace=False, p=p).astype(np.int32)
+        qs.append((ids, rng.uniform(0.5, 1.5, size=m).astype(np.float32)))
+    qs[7] = (np.zeros(0, np.int32), np.zeros(0, np.float32))            # no terms
+    qs[11] = (np.array([5], np.int32), np.ones(1, np.float32))         # a term no row carries
+    for group in ("8", "4", "2"):
+        monkeypatch.setenv("VR_SPARSE_GROUP", group)
+        for flt, mask in ((None, live.astype(bool)), (SearchFilter(include_folders=[0, 2, 5]), live.astype(bool) & np.isin(folder, [0, 2, 5]))):
+            for k in (1, 10, 30, 64):
+                before = e.stats()
+                got = e.search_sparse_batch(qs, k, flt)
+                after = e.stats()
+                assert after["sparse_grouped"] - before["sparse_grouped"] == len(qs)
+                assert after["sparse_group_redo"] == before["sparse_group_redo"]
+                for i, (qi, qv) in enumerate(qs):
+                    if len(qi) == 0:
+                        assert len(got[i][0]) == 0
+                        continue
+                    wr, ws = ocore.topk(sp.scores(qi, qv), k, mask.astype(np.uint8))
+                    assert np.array_equal(got[i][0], wr), (group, k, i)
+                    assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), (group, k, i)
+    monkeypatch.delenv("VR_SPARSE_GROUP")
+    want = e.search_sparse_batch(qs, 30)
+    monkeypatch.setenv("VR_SPARSE_GROUPED", "0")
+    before = e.stats()
+    plain = e.search_sparse_batch(qs, 30)
+    assert e.stats()["sparse_grouped"] == before["sparse_grouped"]
+    monkeypatch.delenv("VR_SPARSE_GROUPED")
+    monkeypatch.setenv("VR_SPARSE_GROUP_CAP", "2")
+    before = e.stats()
+    redone = e.search_sparse_batch(qs, 30)
+    assert e.stats()["sparse_group_redo"] == before["sparse_group_redo"] + 1
+    for a, b, c in zip(want, plain, redone):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+
+
 def test_sparse_batch_with_given_weights(small):
     e, rng, x, sp, folder, live, vocab = small
     qs = [(np.sort(rng.choice(vocab, size=4, replace=False)).astype(np.int32) * 7919 + 13, rng.uniform(0.1, 3.0, size=4).astype(np.float32))

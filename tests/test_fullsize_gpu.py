@@ -341,7 +341,11 @@ def test_configs4_shard_hybrid_batch_1p25m_x_1024_with_sparse_rows(gpu):
     e.delete_rows(gone)
     before = e.stats()
     got = e.search_hybrid_batch(qs, sq, limit, w)
-    assert e.stats()["batched"] - before["batched"] == nq
+    after = e.stats()
+    assert after["batched"] - before["batched"] == nq
+    # the sparse legs took the grouped scan (csrc/invert.hip: groups of queries per segment block, thresholds from a
+    # sample of the segments) and no batch had to be redone on the per-query kernels
+    assert after["sparse_grouped"] - before["sparse_grouped"] == nq and after["sparse_group_redo"] == before["sparse_group_redo"]
     got_rrf = e.search_hybrid_batch(qs, sq, limit, w, fusion=VR_FUSION_RRF)
     for i in range(nq):
         r1, s1, f1 = e.search_hybrid(qs[i], sq[i][0], sq[i][1], limit, w)

@@ -307,6 +307,9 @@ struct SearchLane {
     m->stat_batched += L->stat_batched.exchange(0);
     m->stat_batch_fallback += L->stat_batch_fallback.exchange(0);
     m->stat_batch_cands += L->stat_batch_cands.exchange(0);
+    m->stat_sparse_grouped += L->stat_sparse_grouped.exchange(0);
+    m->stat_sparse_group_redo += L->stat_sparse_group_redo.exchange(0);
+    m->stat_sparse_group_cands += L->stat_sparse_group_cands.exchange(0);
     const int64_t lc = L->stat_last_candidates.exchange(-1);
     if (lc >= 0) m->stat_last_candidates.store(lc);
     if (lock.owns_lock()) lock.unlock();
@@ -711,6 +714,9 @@ int vr_stats(vr_engine* e, int32_t which, int64_t* out) {
     case VR_STAT_BATCH_FALLBACK: *out = e->stat_batch_fallback.load(); break;
     case VR_STAT_BATCH_CANDIDATES: *out = e->stat_batch_cands.load(); break;
     case VR_STAT_GENERATION: *out = e->generation.load(); break;
+    case VR_STAT_SPARSE_GROUPED: *out = e->stat_sparse_grouped.load(); break;
+    case VR_STAT_SPARSE_GROUP_REDO: *out = e->stat_sparse_group_redo.load(); break;
+    case VR_STAT_SPARSE_GROUP_CANDIDATES: *out = e->stat_sparse_group_cands.load(); break;
     default: set_error("unknown statistic %d", which); return -1;
   }
   return 0;
@@ -1045,7 +1051,8 @@ int prepare_sparse_batch(const int64_t* q_off, const int32_t* q_idx, const float
 }
 
 // Queues the batch kernel of the prepared queries on e->stream; the nq x k keys end up in e->sq_keys (device).
-int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool weights_given, const uint8_t* mask) {
+int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool weights_given, const uint8_t* mask,
+                        bool allow_grouped = true) {
   const int64_t nt = static_cast<int64_t>(b.ids.size());
   VR_TRY(e->sq_off.grow(nq + 1, 0, e->stream));
   VR_TRY(e->sq_ids.grow(std::max<int64_t>(nt, 1), 0, e->stream));
@@ -1060,7 +1067,21 @@ int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool 
   VR_HIP(hipMemcpyAsync(e->sq_ids.p, b.ids.data(), sizeof(int32_t) * static_cast<size_t>(nt), hipMemcpyHostToDevice, e->stream));
   VR_HIP(hipMemcpyAsync(e->sq_val.p, b.vals.data(), sizeof(float) * static_cast<size_t>(nt), hipMemcpyHostToDevice, e->stream));
   return inv_scan_topk_batch(e, e->sq_off.p, e->sq_ids.p, e->sq_val.p, e->sq_w.p, nq, static_cast<int>(nt), weights_given,
-                             static_cast<float>(e->n_sparse_points), mask, k, e->sq_keys.p);
+                             static_cast<float>(e->n_sparse_points), mask, k, e->sq_keys.p, b.off.data(), b.ids.data(),
+                             allow_grouped);
+}
+
+// After the stream of sparse_batch_launch has been synchronised: the grouped scan gives a batch up when a query's
+// candidate buffer overflows (invert.hip) — the batch is then repeated on the per-query kernels, whose answer does not
+// depend on any budget. Runs on e->stream and waits for it.
+int sparse_batch_redo_if_overflowed(vr_engine* e, const SparseBatch& b, int nq, int k, bool weights_given, const uint8_t* mask,
+                                    uint64_t* keys_host) {
+  if (*pin_host<int32_t>(e, kPinSparseOverflow) == 0) return 0;
+  e->stat_sparse_group_redo.fetch_add(1);
+  VR_TRY(sparse_batch_launch(e, b, nq, k, weights_given, mask, false));
+  VR_HIP(hipMemcpyAsync(keys_host, e->sq_keys.p, sizeof(uint64_t) * static_cast<size_t>(nq) * k, hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  return 0;
 }
 
 // The queries the batch kernel could not take, one at a time through the single-query scans (e->stream); their keys
@@ -1089,6 +1110,7 @@ int search_sparse_keys_locked(vr_engine* e, const int64_t* q_off, const int32_t*
   VR_TRY(sparse_batch_launch(e, b, nq, k, weights_given, mask));
   VR_HIP(hipMemcpyAsync(keys_host, e->sq_keys.p, sizeof(uint64_t) * static_cast<size_t>(nq) * k, hipMemcpyDeviceToHost, e->stream));
   VR_HIP(hipStreamSynchronize(e->stream));
+  VR_TRY(sparse_batch_redo_if_overflowed(e, b, nq, k, weights_given, mask, keys_host));
   return sparse_batch_stragglers(e, b, q_off, q_idx, q_val, k, weights_given, mask, keys_host);
 }
 
@@ -1137,6 +1159,7 @@ int hybrid_keys_locked(vr_engine* e, const float* q, int nq, int mem, const int6
   VR_TRY(search_dense_keys_locked(e, q, nq, mem, k, filter, dense_host, nullptr, mask));
   if (have_sparse) {
     VR_HIP(hipStreamSynchronize(e->aux_stream));
+    VR_TRY(sparse_batch_redo_if_overflowed(e, b, nq, k, weights_given, mask, sparse_host));
     VR_TRY(sparse_batch_stragglers(e, b, sq_off, sq_idx, sq_val, k, weights_given, mask, sparse_host));
   }
   return 0;

@@ -30,6 +30,10 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <iterator>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace vr {
 
@@ -1113,6 +1117,488 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
   if (threadIdx.x < kListLen) cand_out[slot * kListLen + threadIdx.x] = sh.lists[threadIdx.x];
 }
 
+// ---- many queries per launch, GROUPED: every term's postings added up, once per group of queries -----------------------
+//
+// The kernels above spend a block (or a wave) per (segment share, query): a thousand queries drawn from one vocabulary walk
+// the same long runs of the same common terms a thousand times, and each walk is a chain of memory round trips (search,
+// postings, forward rows) with one query's worth of work behind it. Here a block takes one SEGMENT and a GROUP of G
+// queries (the host sorts the batch so that queries which share their commonest terms sit together):
+//   locate   one launch finds, for every DISTINCT term of the batch and every segment, the term's run of postings
+//            (64-way searches, four terms x {first, past-the-last} per wave in flight together; thousands of waves in
+//            flight), a second one lays the bounds out per (segment, group, union term) and fills in the weights — so a
+//            scan block's first loads depend on nothing but its block index;
+//   scan     the runs of the group's union of terms, compacted, are ONE stream of postings: a thread takes positions
+//            tid, tid + 512, ... of it, kGrpSlices loads in flight per thread and batch, two batches in flight. A posting
+//            of term u adds fl(w_g * v) to the accumulator plane of every query g of the group that carries u: G planes
+//            of 4096 f32 in LDS. A slice of 512 positions is taken term by term in ascending id order, and a barrier
+//            separates two terms whenever a query carries both (one term's postings name distinct rows; terms of
+//            different queries touch different planes), so every (query, row) sum is built in the forward scan's order
+//            from +0.0: the same bits as sparse_inv_kernel and sparse.hip.
+//   select   the seed pass (sparse_inv_pruned_kernel<true>) gave every query k real rows with real scores; only rows whose
+//            key reaches the k-th of them can be among the final k, and those few are appended to the query's candidate
+//            buffer (an atomic counter per query); select_counted_kernel ranks each buffer. A query without a full seed
+//            list offers every row it shares a term with; a buffer that overflows (kGrpCandCap keys) makes the host
+//            repeat the batch on the per-query kernels — the answer never depends on the threshold being good.
+// Bytes: 12 B per posting of the UNION of a group's terms per segment (served by L2 / Infinity Cache: the blocks of one
+// segment run together, blockIdx.x = group), against 12 B per posting, query and term before.
+constexpr int kGrpThreads = 512;
+constexpr int kGrpMaxU = 64;     // union terms of a group (the host closes a group before it exceeds this): one per lane
+constexpr int kGrpSlices = 8;    // postings per thread and batch (two batches in flight)
+constexpr int kGrpPer = 2;       // ... of which a thread adds up this many together
+constexpr int kGrpHdr = 4 + 8;   // ints per group: union size, 3 spare, the (<= 8) queries' numbers (-1: none)
+constexpr int kGrpEnt = 2 + 8;   // ints per union term: slot of the term among the batch's distinct terms, query mask,
+                                 // per query the index of its weight in q_w (-1: none)
+constexpr int kGrpSearch = 4;    // terms a wave searches together
+constexpr int kGrpCandCap = 16;  // candidate keys per (query, segment), at least
+
+// first posting of term t[i] and first posting past it, for kGrpSearch terms at once: 2 kGrpSearch independent 64-way
+// searches whose probes are in flight together (the steps of inv_wave_lower_bound, same invariants)
+__device__ __forceinline__ void inv_wave_runs(const uint64_t* __restrict__ kp, int count, const int32_t (&t)[kGrpSearch],
+                                              int lane, int (&first)[kGrpSearch], int (&past)[kGrpSearch]) {
+  constexpr int C = 2 * kGrpSearch;
+  int lo[C], hi[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    lo[c] = 0;
+    hi[c] = count;
+  }
+  for (;;) {
+    int widest = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) widest = max(widest, hi[c] - lo[c]);
+    if (widest <= 64) break;  // wave-uniform
+    uint64_t key[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int step = (hi[c] - lo[c] + 63) >> 6;
+      key[c] = kp[min(lo[c] + lane * step, count - 1)];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int step = (hi[c] - lo[c] + 63) >> 6;
+      const int p = lo[c] + lane * step;
+      const int32_t term = inv_term(key[c]);
+      const int32_t tt = t[c % kGrpSearch];
+      const bool less = p < hi[c] && (c < kGrpSearch ? term < tt : term <= tt);
+      const int n = __popcll(__ballot(less));
+      const int nlo = n ? lo[c] + (n - 1) * step + 1 : lo[c];
+      const int nhi = n < 64 ? min(hi[c], lo[c] + n * step) : hi[c];
+      lo[c] = nlo;
+      hi[c] = nhi;
+    }
+  }
+  uint64_t key[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) key[c] = kp[min(lo[c] + lane, count - 1)];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int p = lo[c] + lane;
+    const int32_t term = inv_term(key[c]);
+    const int32_t tt = t[c % kGrpSearch];
+    const bool less = p < hi[c] && (c < kGrpSearch ? term < tt : term <= tt);
+    const int res = lo[c] + __popcll(__ballot(less));
+    if (c < kGrpSearch) first[c] = res;
+    else past[c - kGrpSearch] = res;
+  }
+}
+
+// bounds[seg][slot] = (first posting, postings) of the batch's distinct term `slot` in segment `seg` (relative to the segment)
+__global__ __launch_bounds__(256) void sparse_inv_locate_kernel(const InvSeg* __restrict__ segs,
+                                                                const uint64_t* __restrict__ keys,
+                                                                const int32_t* __restrict__ slot_terms, int n_slots,
+                                                                int2* __restrict__ bounds) {
+  const int lane = threadIdx.x & 63;
+  const int s0 = (static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6)) * kGrpSearch;
+  if (s0 >= n_slots) return;  // wave-uniform
+  const InvSeg seg = segs[blockIdx.y];
+  int2* out = bounds + static_cast<int64_t>(blockIdx.y) * n_slots + s0;
+  int first[kGrpSearch] = {0, 0, 0, 0}, past[kGrpSearch] = {0, 0, 0, 0};
+  if (seg.count > 0) {
+    int32_t t[kGrpSearch];
+#pragma unroll
+    for (int i = 0; i < kGrpSearch; ++i) t[i] = slot_terms[min(s0 + i, n_slots - 1)];
+    inv_wave_runs(keys + seg.off, seg.count, t, lane, first, past);
+  }
+#pragma unroll
+  for (int i = 0; i < kGrpSearch; ++i)
+    if (lane == i && s0 + i < n_slots) out[i] = make_int2(first[i], past[i] - first[i]);
+}
+
+// per (segment, group, union term): the bounds of its slot; and (blockIdx.y == 0) per (group, union term, query) the weight
+__global__ __launch_bounds__(256) void sparse_inv_expand_kernel(const int2* __restrict__ bounds, int n_slots,
+                                                                const int32_t* __restrict__ ent, int n_gu, int n_seg,
+                                                                const float* __restrict__ q_w, int2* __restrict__ out,
+                                                                float* __restrict__ ent_w) {
+  const int gu = blockIdx.x * 256 + threadIdx.x;
+  if (gu >= n_gu) return;
+  const int32_t slot = ent[static_cast<int64_t>(gu) * kGrpEnt];
+  for (int s = blockIdx.y; s < n_seg; s += gridDim.y)
+    out[static_cast<int64_t>(s) * n_gu + gu] = slot >= 0 ? bounds[static_cast<int64_t>(s) * n_slots + slot] : make_int2(0, 0);
+  if (blockIdx.y == 0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int32_t wi = ent[static_cast<int64_t>(gu) * kGrpEnt + 2 + g];
+      ent_w[static_cast<int64_t>(gu) * 8 + g] = wi >= 0 ? q_w[wi] : 0.0f;
+    }
+  }
+}
+
+// theta[group][g] = the threshold key of query g of the group: the k-th key of its seed list
+__global__ void sparse_inv_theta_kernel(const int32_t* __restrict__ hdr, int n_groups, const uint64_t* __restrict__ seed_keys,
+                                        int k, uint64_t* __restrict__ theta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_groups * 8) return;
+  const int32_t q = hdr[static_cast<int64_t>(i / 8) * kGrpHdr + 4 + i % 8];
+  theta[i] = q >= 0 ? seed_keys[static_cast<int64_t>(q) * k + (k - 1)] : ~0ull;
+}
+
+// "no term of the query names this row yet": an accumulator's initial bits. A NaN no arithmetic produces (results carry
+// the canonical quiet NaN or an operand's payload; a caller would have to store a weight with exactly these bits).
+constexpr uint32_t kGrpUntouched = 0xFFFFFFFFu;
+
+// SAMPLE: the block takes segment blockIdx.y * seg_stride and, instead of the rows that reach a threshold, leaves the best
+// key of each of its waves' 512 rows per query (8 real rows with real scores per (query, sampled segment)): the k-th best
+// of a query's sample is the threshold of the full pass.
+template <int G, bool SAMPLE>
+__global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
+    const InvSeg* __restrict__ segs, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
+    const int32_t* __restrict__ grp_hdr, const int32_t* __restrict__ grp_ent, const float* __restrict__ ent_w,
+    const int2* __restrict__ bounds, int stride_u, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ theta,
+    uint64_t* __restrict__ cand, int32_t* __restrict__ cnt, int cap, int dbg_mode, int seg_stride) {
+  static_assert(G >= 1 && G <= 8, "group size");
+  __shared__ __align__(16) float acc[G * kInvSegRows];
+  __shared__ int32_t s_mask[kGrpMaxU];         // by compacted run: the queries that carry its term
+  __shared__ int32_t s_lo[kGrpMaxU];           //                   its first posting
+  __shared__ int32_t s_pre[kGrpMaxU + 1];      //                   its first position in the stream (s_pre[n_c] = the total)
+  __shared__ float s_w[kGrpMaxU * G];          //                   the queries' weights
+  __shared__ uint64_t s_theta[G];
+  __shared__ int32_t s_q[G];
+  __shared__ int32_t s_nc;
+  __shared__ int32_t s_cnt[G];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = blockIdx.x;
+  const int seg_no = SAMPLE ? static_cast<int>(blockIdx.y) * seg_stride : static_cast<int>(blockIdx.y);
+  const InvSeg seg = segs[seg_no];
+  const int64_t gu0 = static_cast<int64_t>(grp) * stride_u;
+  // the filter bytes of the 8 rows this thread will look at when the sums are complete (rows past the segment: 0)
+  uint64_t pass8 = 0ull;
+  {
+    const int r0 = tid * 8;
+    const uint8_t* mp = mask + seg.row_base + r0;
+    if (r0 + 8 <= seg.nrows && (reinterpret_cast<uintptr_t>(mp) & 7u) == 0) {
+      pass8 = *reinterpret_cast<const uint64_t*>(mp);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r0 + j < seg.nrows) pass8 |= static_cast<uint64_t>(mp[j]) << (8 * j);
+    }
+  }
+  if (tid < G) s_cnt[tid] = 0;
+  if (tid < 64) {  // wave 0: the group's union terms, one per lane; the runs that are not empty, compacted
+    const bool in = lane < stride_u;
+    const int2 b = in ? bounds[(static_cast<int64_t>(seg_no) * gridDim.x + grp) * stride_u + lane] : make_int2(0, 0);
+    const int32_t m = in ? grp_ent[(gu0 + lane) * kGrpEnt + 1] & ((1 << G) - 1) : 0;
+    float w[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) w[g] = in ? ent_w[(gu0 + lane) * 8 + g] : 0.0f;
+    const int len = m ? b.y : 0;
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    const uint64_t live = __ballot(len > 0);
+    const int ci = __popcll(live & ((1ull << lane) - 1ull));
+    if (len > 0) {
+      s_mask[ci] = m;
+      s_lo[ci] = b.x;
+      s_pre[ci] = incl - len;
+#pragma unroll
+      for (int g = 0; g < G; ++g) s_w[ci * G + g] = w[g];
+    }
+    if (lane == 63) {
+      s_pre[__popcll(live)] = incl;
+      s_nc = __popcll(live);
+    }
+  } else if (tid < 64 + G) {
+    const int g = tid - 64;
+    s_q[g] = grp_hdr[static_cast<int64_t>(grp) * kGrpHdr + 4 + g];
+    s_theta[g] = SAMPLE ? 0ull : theta[static_cast<int64_t>(grp) * 8 + g];
+  }
+  {
+    uint4* a4 = reinterpret_cast<uint4*>(acc);
+    for (int i = tid; i < G * kInvSegRows / 4; i += kGrpThreads)
+      a4[i] = make_uint4(kGrpUntouched, kGrpUntouched, kGrpUntouched, kGrpUntouched);
+  }
+  __syncthreads();
+  const int n_c = s_nc;
+  const int total = s_pre[n_c];
+  if (total == 0 || (dbg_mode & 4)) return;  // block-uniform: no term of the group occurs in this segment
+  const uint64_t* kp = keys + seg.off;
+  const float* vp = vals + seg.off;
+  // the run table once more, in registers: lane c of every wave holds run c (block-uniform reads are v_readlane then,
+  // not LDS round trips)
+  const int r_pre = lane <= n_c ? s_pre[lane] : 0x7FFFFFFF;
+  const int r_mask = lane < n_c ? s_mask[lane] : 0;
+  float r_w[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) r_w[g] = lane < n_c ? s_w[lane * G + g] : 0.0f;
+  // lane 64 does not exist: the total is kept aside for n_c == 64
+  auto pre_of = [&](int c) { return c >= 64 ? total : __builtin_amdgcn_readlane(r_pre, c); };
+
+  // the stream of postings, kGrpSlices x 512 positions per batch; batch b + 1 is requested before batch b is added up
+  constexpr int kBatch = kGrpSlices * kGrpThreads;
+  uint64_t bk[2][kGrpSlices];
+  float bv[2][kGrpSlices];
+  int bc[2][kGrpSlices];  // the compacted run a position belongs to
+  int pc = 0;             // this thread's walk through s_pre (positions only grow)
+  int pend = s_pre[1];    // ... the end of run pc in the stream, and what turns a position of it into a posting
+  int pdelta = s_lo[0] - s_pre[0];
+  auto request = [&](int set, int base) {
+#pragma unroll
+    for (int j = 0; j < kGrpSlices; ++j) {
+      const int i = base + j * kGrpThreads + tid;
+      const int ic = i < total ? i : total - 1;
+      while (ic >= pend) {
+        ++pc;
+        pend = s_pre[pc + 1];
+        pdelta = s_lo[pc] - s_pre[pc];
+      }
+      bc[set][j] = pc;
+      bk[set][j] = kp[ic + pdelta];
+      bv[set][j] = vp[ic + pdelta];
+    }
+  };
+  unsigned dirty = 0u;  // queries whose planes have been written since the last barrier
+  int su = 0;           // block-uniform walk through the runs
+  // a batch is added up kGrpPer x 512 positions at a time (a thread holds kGrpPer of them, 512 apart): the planes' sums of
+  // all its rows are requested together, then the runs the positions belong to are taken in ascending term id
+  auto add_up = [&](int set, int base) {
+#pragma unroll
+    for (int j0 = 0; j0 < kGrpSlices; j0 += kGrpPer) {
+      const int s0 = base + j0 * kGrpThreads;
+      if (s0 >= total) break;  // block-uniform
+      const int s1 = min(s0 + kGrpPer * kGrpThreads, total);
+      while (s0 >= pre_of(su + 1)) ++su;
+      int r[kGrpPer], mine[kGrpPer];
+      float val[kGrpPer], a[kGrpPer][G];
+#pragma unroll
+      for (int v = 0; v < kGrpPer; ++v) {
+        const int i = s0 + v * kGrpThreads + tid;
+        r[v] = static_cast<int>(bk[set][j0 + v] & (kInvSegRows - 1));
+        val[v] = bv[set][j0 + v];
+        mine[v] = (i < total && !(dbg_mode & 1)) ? bc[set][j0 + v] : -1;
+        if ((dbg_mode & 9) && (bk[set][j0 + v] >> 50) == 0x3FFFull && val[v] == 1.25f) acc[0] = val[v];  // (diagnostics: keeps the loads alive)
+      }
+      if (dbg_mode & 8) continue;
+      // every plane's sum of these rows, requested together (a read the posting may not need costs nothing but LDS
+      // bandwidth; the writes below are conditional — another term's thread may own the planes this term does not touch)
+#pragma unroll
+      for (int v = 0; v < kGrpPer; ++v)
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[v][g] = acc[g * kInvSegRows + r[v]];
+      for (int c = su; c < n_c; ++c) {  // block-uniform: the runs these positions touch, ascending term id
+        const int c_pre = pre_of(c);
+        if (c_pre >= s1) break;
+        const unsigned m = static_cast<unsigned>(__builtin_amdgcn_readlane(r_mask, c));
+        if (c_pre >= s0) {  // (a run that began earlier has been through this: its own postings name distinct rows)
+          if (m & dirty) {  // a query of this term has been added to since the last barrier: its earlier term comes first
+            __syncthreads();
+            dirty = 0u;
+#pragma unroll
+            for (int v = 0; v < kGrpPer; ++v)
+              if (mine[v] >= c) {  // (the sums read above may be stale now)
+#pragma unroll
+                for (int g = 0; g < G; ++g) a[v][g] = acc[g * kInvSegRows + r[v]];
+              }
+          }
+          dirty |= m;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (m & (1u << g)) {  // block-uniform
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r_w[g]), c));
+#pragma unroll
+            for (int v = 0; v < kGrpPer; ++v)
+              if (mine[v] == c) {
+                const float from = __float_as_uint(a[v][g]) == kGrpUntouched ? 0.0f : a[v][g];
+                acc[g * kInvSegRows + r[v]] = __fadd_rn(from, __fmul_rn(w, val[v]));
+              }
+          }
+      }
+    }
+  };
+  request(0, 0);
+  for (int base = 0; base < total; base += 2 * kBatch) {  // block-uniform
+    if (base + kBatch < total) request(1, base + kBatch);
+    add_up(0, base);
+    if (base + kBatch >= total) break;
+    if (base + 2 * kBatch < total) request(0, base + 2 * kBatch);
+    add_up(1, base + kBatch);
+  }
+  __syncthreads();
+  if (dbg_mode & 2) return;
+
+  // The rows that reach their query's threshold key (the seed's k-th: k real rows are at or above it) go to the
+  // (query, segment) region of the candidate array — this block's own, so a slot costs an LDS atomic and the block ends
+  // without a global round trip (the rows' filter bytes were requested in the prologue). A thread takes 8 consecutive rows.
+  {
+    const int r0 = tid * 8;
+    uint32_t sc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint4 lo4 = *reinterpret_cast<const uint4*>(acc + g * kInvSegRows + r0);
+      const uint4 hi4 = *reinterpret_cast<const uint4*>(acc + g * kInvSegRows + r0 + 4);
+      sc[g][0] = lo4.x, sc[g][1] = lo4.y, sc[g][2] = lo4.z, sc[g][3] = lo4.w;
+      sc[g][4] = hi4.x, sc[g][5] = hi4.y, sc[g][6] = hi4.z, sc[g][7] = hi4.w;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int32_t q = s_q[g];
+      if (q < 0) continue;  // block-uniform
+      const uint64_t th = s_theta[g];
+      const uint32_t th_hi = static_cast<uint32_t>(th >> 32);
+      uint64_t* region = cand + (static_cast<int64_t>(q) * gridDim.y + blockIdx.y) * cap;
+      uint64_t best = 0ull;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t bits = sc[g][j];
+        if (bits == kGrpUntouched || !((pass8 >> (8 * j)) & 0xFFull)) continue;
+        const uint32_t u = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);  // (the key's upper half, topk_make_key)
+        if (u < th_hi) continue;
+        const uint64_t key = topk_make_key(__uint_as_float(bits), static_cast<int64_t>(seg.row_base) + r0 + j);
+        if (key == 0ull || key < th) continue;
+        if (SAMPLE) {
+          best = key > best ? key : best;
+        } else {
+          const int slot = atomicAdd(&s_cnt[g], 1);
+          if (slot < cap) region[slot] = key;
+        }
+      }
+      if (SAMPLE) {  // the wave's best key (cap >= 8: one slot per wave)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t o = __shfl_xor(best, off);
+          best = o > best ? o : best;
+        }
+        if (lane == 0) region[tid >> 6] = best;
+      }
+    }
+  }
+  if (SAMPLE) {
+    if (tid < G && s_q[tid] >= 0) cnt[static_cast<int64_t>(s_q[tid]) * gridDim.y + blockIdx.y] = kGrpThreads / 64;
+    return;
+  }
+  __syncthreads();
+  if (tid < G && s_q[tid] >= 0) cnt[static_cast<int64_t>(s_q[tid]) * gridDim.y + blockIdx.y] = s_cnt[tid];
+}
+
+// The group tables of a batch (host): queries are ordered so that those which share their commonest terms (by the
+// number of queries of THIS batch that carry a term) are neighbours, then cut into groups of <= G queries whose union of
+// terms stays <= kGrpMaxU. tables: [n_groups x kGrpHdr][n_groups x stride_u x kGrpEnt][n_slots distinct terms, ascending].
+struct GroupLayout {
+  int n_groups = 0, stride_u = 0, n_slots = 0;
+  int64_t ent_off = 0, slot_off = 0;
+};
+static GroupLayout inv_group_queries(const int32_t* off, const int32_t* ids, int nq, int G, std::vector<int32_t>* out) {
+  std::unordered_map<int32_t, int32_t> freq;
+  freq.reserve(static_cast<size_t>(off[nq]) * 2 + 16);
+  for (int32_t i = off[0]; i < off[nq]; ++i) ++freq[ids[i]];
+  std::vector<int32_t> slots;
+  slots.reserve(freq.size());
+  for (const auto& kv : freq) slots.push_back(kv.first);
+  std::sort(slots.begin(), slots.end());
+  struct Q {
+    int32_t q;
+    int32_t key[6];  // (-frequency, id) of its three commonest terms
+  };
+  std::vector<Q> order;
+  order.reserve(static_cast<size_t>(nq));
+  std::vector<std::pair<int32_t, int32_t>> t;
+  for (int q = 0; q < nq; ++q) {
+    const int n = off[q + 1] - off[q];
+    if (n <= 0) continue;
+    t.clear();
+    for (int j = 0; j < n; ++j) t.emplace_back(-freq[ids[off[q] + j]], ids[off[q] + j]);
+    const size_t top = std::min<size_t>(3, t.size());
+    std::partial_sort(t.begin(), t.begin() + static_cast<std::ptrdiff_t>(top), t.end());
+    Q e{q, {0, 0, 0, 0, 0, 0}};
+    for (size_t j = 0; j < top; ++j) {
+      e.key[2 * j] = t[j].first;
+      e.key[2 * j + 1] = t[j].second;
+    }
+    order.push_back(e);
+  }
+  std::sort(order.begin(), order.end(), [](const Q& a, const Q& b) {
+    for (int j = 0; j < 6; ++j)
+      if (a.key[j] != b.key[j]) return a.key[j] < b.key[j];
+    return a.q < b.q;
+  });
+  // the groups: members and their union of terms
+  std::vector<std::vector<int32_t>> groups;
+  std::vector<int32_t> members, uni, merged;
+  size_t widest = 0;
+  for (const Q& e : order) {
+    const int32_t* a = ids + off[e.q];
+    const int n = off[e.q + 1] - off[e.q];
+    merged.clear();
+    std::set_union(uni.begin(), uni.end(), a, a + n, std::back_inserter(merged));
+    if (!members.empty() && (static_cast<int>(members.size()) >= G || static_cast<int>(merged.size()) > kGrpMaxU)) {
+      widest = std::max(widest, uni.size());
+      groups.push_back(members);
+      members.clear();
+      merged.assign(a, a + n);
+    }
+    uni.swap(merged);
+    members.push_back(e.q);
+  }
+  if (!members.empty()) {
+    widest = std::max(widest, uni.size());
+    groups.push_back(members);
+  }
+  GroupLayout lay;
+  lay.n_groups = static_cast<int>(groups.size());
+  lay.stride_u = static_cast<int>(std::min<size_t>(kGrpMaxU, (widest + 7) / 8 * 8));
+  lay.n_slots = static_cast<int>(slots.size());
+  lay.ent_off = static_cast<int64_t>(lay.n_groups) * kGrpHdr;
+  lay.slot_off = lay.ent_off + static_cast<int64_t>(lay.n_groups) * lay.stride_u * kGrpEnt;
+  out->assign(static_cast<size_t>(lay.slot_off) + slots.size(), -1);
+  int32_t* hdr = out->data();
+  int32_t* ent = out->data() + lay.ent_off;
+  std::copy(slots.begin(), slots.end(), out->begin() + static_cast<std::ptrdiff_t>(lay.slot_off));
+  struct Trip {
+    int32_t term, g, widx;
+  };
+  std::vector<Trip> trips;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    trips.clear();
+    for (size_t g = 0; g < groups[gi].size(); ++g) {
+      const int q = groups[gi][g];
+      for (int32_t i = off[q]; i < off[q + 1]; ++i) trips.push_back(Trip{ids[i], static_cast<int32_t>(g), i});
+      hdr[gi * kGrpHdr + 4 + g] = q;
+    }
+    std::sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.term != b.term ? a.term < b.term : a.g < b.g; });
+    int32_t n_u = 0;
+    for (size_t i = 0; i < trips.size();) {
+      int32_t* row = ent + (gi * static_cast<size_t>(lay.stride_u) + static_cast<size_t>(n_u)) * kGrpEnt;
+      row[0] = static_cast<int32_t>(std::lower_bound(slots.begin(), slots.end(), trips[i].term) - slots.begin());
+      row[1] = 0;
+      size_t j = i;
+      for (; j < trips.size() && trips[j].term == trips[i].term; ++j) {
+        row[1] |= 1 << trips[j].g;
+        row[2 + trips[j].g] = trips[j].widx;
+      }
+      ++n_u;
+      i = j;
+    }
+    hdr[gi * kGrpHdr] = n_u;
+    // (unused union entries keep slot -1 and, below, mask 0)
+    for (int u = n_u; u < lay.stride_u; ++u) ent[(gi * static_cast<size_t>(lay.stride_u) + static_cast<size_t>(u)) * kGrpEnt + 1] = 0;
+  }
+  return lay;
+}
+
 int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, bool weights_given,
                   float n_points, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev) {
   VR_CHECK(nnz >= 1 && nnz <= kInvMaxTerms && k >= 1 && k <= kListLen, "bad inverted-scan shape");
@@ -1135,12 +1621,89 @@ int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
   return topk_merge_lists(e, e->sp_cand.p, blocks, 1, k, out_keys_dev);
 }
 
+// The grouped scan of a batch (see sparse_inv_group_kernel). out_keys_dev: in — the seed lists (sampled == false), out — the
+// nq x k result keys. *done = false: no query of the batch has terms (nothing was launched). Closes the profiler slot.
+static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev,
+                            const int32_t* q_off_host, const int32_t* q_ids_host, bool sampled, bool* done) {
+  const int want_group = std::getenv("VR_SPARSE_GROUP") ? atoi(std::getenv("VR_SPARSE_GROUP")) : 4;
+  const int group_size = want_group == 2 || want_group == 8 ? want_group : 4;  // (4: two blocks per CU; measured best)
+  const int dbg_mode = std::getenv("VR_SPARSE_GROUP_DBG") ? atoi(std::getenv("VR_SPARSE_GROUP_DBG")) : 0;  // timing experiments
+  const int64_t n_seg = e->n_inv_seg;
+  // keys per (query, segment) region: 32 at a million rows (250 segments), more while the segments are few (a region may
+  // then hold most of a query's k best), <= 8192 per query in all
+  const int fit_cap = static_cast<int>(std::max<int64_t>(kGrpCandCap, std::min<int64_t>(512, 8192 / std::max<int64_t>(n_seg, 1))));
+  const int cand_cap = std::getenv("VR_SPARSE_GROUP_CAP") ? std::min(fit_cap, std::max(1, atoi(std::getenv("VR_SPARSE_GROUP_CAP")))) : fit_cap;
+  const GroupLayout lay = inv_group_queries(q_off_host, q_ids_host, nq, group_size, &e->sq_grp_host);
+  *done = lay.n_groups > 0;
+  if (!*done) return 0;
+  const int64_t n_gu = static_cast<int64_t>(lay.n_groups) * lay.stride_u;
+  // the sample: every seg_stride-th segment, 8 keys (one per wave of the block) per (query, sampled segment)
+  const int seg_stride = sampled ? static_cast<int>(n_seg / 16) : 1;
+  const int64_t n_samp = sampled ? (n_seg + seg_stride - 1) / seg_stride : 0;
+  constexpr int kSampCap = kGrpThreads / 64;
+  const int64_t cand_main = static_cast<int64_t>(nq) * n_seg * cand_cap, cand_samp = static_cast<int64_t>(nq) * n_samp * kSampCap;
+  const int64_t cnt_main = static_cast<int64_t>(nq) * n_seg + 1, cnt_samp = static_cast<int64_t>(nq) * n_samp;  // (+ the keys ranked)
+  VR_TRY(e->sq_grp.grow(static_cast<int64_t>(e->sq_grp_host.size()), 0, e->stream));
+  VR_TRY(e->sq_cnt.grow(cnt_main + cnt_samp, 0, e->stream));
+  VR_TRY(e->sq_cand.grow(cand_main + cand_samp + static_cast<int64_t>(lay.n_groups) * 8, 0, e->stream));
+  // run bounds per (segment, distinct term), then per (segment, group, union term); the weights per (group, union term, query)
+  VR_TRY(e->sq_bounds.grow(2 * (n_seg * lay.n_slots + n_seg * n_gu), 0, e->stream));
+  VR_TRY(e->sq_entw.grow(n_gu * 8, 0, e->stream));
+  int2* slot_bounds = reinterpret_cast<int2*>(e->sq_bounds.p);
+  int2* grp_bounds = slot_bounds + n_seg * lay.n_slots;
+  uint64_t* samp_cand = e->sq_cand.p + cand_main;
+  uint64_t* theta = samp_cand + cand_samp;
+  int32_t* samp_cnt = e->sq_cnt.p + cnt_main;
+  const int32_t* hdr = e->sq_grp.p;
+  const int32_t* ent = e->sq_grp.p + lay.ent_off;
+  VR_HIP(hipMemcpyAsync(e->sq_grp.p, e->sq_grp_host.data(), sizeof(int32_t) * e->sq_grp_host.size(), hipMemcpyHostToDevice, e->stream));
+  VR_HIP(hipMemsetAsync(e->sq_cnt.p, 0, sizeof(int32_t) * static_cast<size_t>(cnt_main + cnt_samp), e->stream));
+  hipLaunchKernelGGL(sparse_inv_locate_kernel,
+                     dim3(static_cast<unsigned>((lay.n_slots + 4 * kGrpSearch - 1) / (4 * kGrpSearch)), static_cast<unsigned>(n_seg)),
+                     dim3(256), 0, e->stream, e->inv_seg.p, e->inv_key.p, e->sq_grp.p + lay.slot_off, lay.n_slots, slot_bounds);
+  hipLaunchKernelGGL(sparse_inv_expand_kernel,
+                     dim3(static_cast<unsigned>((n_gu + 255) / 256), static_cast<unsigned>(std::min<int64_t>(n_seg, 64))), dim3(256), 0,
+                     e->stream, slot_bounds, lay.n_slots, ent, static_cast<int>(n_gu), static_cast<int>(n_seg), q_w_dev, grp_bounds,
+                     e->sq_entw.p);
+  auto launch = [&](auto kernel, int64_t rows_y, uint64_t* cand, int32_t* cnt, int cap, int stride) {
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(lay.n_groups), static_cast<unsigned>(rows_y)), dim3(kGrpThreads), 0, e->stream,
+                       e->inv_seg.p, e->inv_key.p, e->inv_val.p, hdr, ent, e->sq_entw.p, grp_bounds, lay.stride_u, mask_dev, theta, cand,
+                       cnt, cap, dbg_mode, stride);
+  };
+  if (sampled) {
+    // thresholds: the sampled segments scanned in full, the best key of every 512 rows kept; the k-th best of a query's
+    // sample (real rows, real scores) is a lower bound of its final k-th best key
+    if (group_size == 2) launch(sparse_inv_group_kernel<2, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
+    else if (group_size == 4) launch(sparse_inv_group_kernel<4, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
+    else launch(sparse_inv_group_kernel<8, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
+    VR_TRY(topk_select_regions(e, samp_cand, static_cast<int>(n_samp), kSampCap, samp_cnt, nq, k, out_keys_dev,
+                               pin_dev<int32_t>(e, kPinSparseOverflow), nullptr));
+  }
+  hipLaunchKernelGGL(sparse_inv_theta_kernel, dim3(static_cast<unsigned>((lay.n_groups * 8 + 255) / 256)), dim3(256), 0, e->stream, hdr,
+                     lay.n_groups, out_keys_dev, k, theta);
+  if (group_size == 2) launch(sparse_inv_group_kernel<2, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
+  else if (group_size == 4) launch(sparse_inv_group_kernel<4, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
+  else launch(sparse_inv_group_kernel<8, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
+  prof_end(e);
+  VR_HIP(hipGetLastError());
+  e->stat_sparse_grouped += nq;
+  int32_t* ranked = e->sq_cnt.p + cnt_main - 1;
+  VR_TRY(topk_select_regions(e, e->sq_cand.p, static_cast<int>(n_seg), cand_cap, e->sq_cnt.p, nq, k, out_keys_dev,
+                             pin_dev<int32_t>(e, kPinSparseOverflow), ranked));
+  VR_HIP(hipMemcpyAsync(pin_host<int32_t>(e, kPinSparseCands), ranked, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+
 // nq queries in device memory (CSR as sparse_inv_batch_kernel takes it, raw values in q_val_dev) -> nq x k keys in
 // out_keys_dev (device-visible). Queries with an empty term range come out as empty lists.
 int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q_ids_dev, const float* q_val_dev,
                         float* q_w_dev, int nq, int n_terms, bool weights_given, float n_points, const uint8_t* mask_dev,
-                        int k, uint64_t* out_keys_dev) {
+                        int k, uint64_t* out_keys_dev, const int32_t* q_off_host, const int32_t* q_ids_host,
+                        bool allow_grouped) {
   VR_CHECK(nq >= 1 && k >= 1 && k <= kListLen, "bad inverted-scan shape");
+  *pin_host<int32_t>(e, kPinSparseOverflow) = 0;
+  e->stat_sparse_group_cands += *pin_host<int32_t>(e, kPinSparseCands);  // (of the batch before: its stream has been waited for)
+  *pin_host<int32_t>(e, kPinSparseCands) = 0;
   if (n_terms > 0)
     hipLaunchKernelGGL(sparse_batch_weights_kernel, dim3(static_cast<unsigned>((n_terms + 255) / 256)), dim3(256), 0,
                        e->stream, q_ids_dev, q_val_dev, n_terms, weights_given ? 1 : 0, e->df_keys.p, e->df_cnt.p, e->df_cap,
@@ -1168,7 +1731,14 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
     VR_HIP(hipMalloc(reinterpret_cast<void**>(&dbg), 8 * sizeof(unsigned long long)));
     VR_HIP(hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), e->stream));
   }
-  if (pruned) {
+  // many queries: groups of queries share a block per segment and every run of the group's terms is read once
+  // (inv_scan_grouped; VR_SPARSE_GROUPED=0 keeps the per-query kernels. The switches are read per call: tests compare the
+  // paths, and force an overflow, in one process)
+  const bool grouped = pruned && !dbg && allow_grouped && q_off_host && q_ids_host && nq >= 16 && e->n_inv_seg <= 65535 &&
+                       !(std::getenv("VR_SPARSE_GROUPED") && atoi(std::getenv("VR_SPARSE_GROUPED")) == 0);
+  // ... with the thresholds from a sample of the segments scanned the same way, once there are enough of them
+  const bool sampled = grouped && e->n_inv_seg >= 128 && !(std::getenv("VR_SPARSE_GROUP_SAMPLE") && atoi(std::getenv("VR_SPARSE_GROUP_SAMPLE")) == 0);
+  if (pruned && !sampled) {
     // 1. seed: per query the k best rows among those that carry its rarest terms, scored exactly -> out_keys_dev; the
     //    k-th of them is a lower bound of the final k-th best score (real rows, real scores)
     hipLaunchKernelGGL((sparse_inv_pruned_kernel<true>), dim3(static_cast<unsigned>(gs), static_cast<unsigned>(nq)), block, 0,
@@ -1177,6 +1747,14 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
                        static_cast<int32_t*>(nullptr), dbg);
     VR_TRY(topk_merge_lists(e, e->sp_cand.p, gs, nq, k, out_keys_dev));
     seed_keys = out_keys_dev;
+  }
+  if (grouped) {
+    bool done = false;
+    VR_TRY(inv_scan_grouped(e, q_w_dev, nq, mask_dev, k, out_keys_dev, q_off_host, q_ids_host, sampled, &done));
+    if (done) return 0;
+    VR_CHECK(!sampled, "the grouped scan found no query with terms");  // (n_terms > 0 here: cannot happen)
+  }
+  if (pruned) {
     // 2. the pruned scan: only the essential terms' postings, from the first segment on; blocks that cannot prune flag
     //    their share
     VR_TRY(e->stage_i32b.grow(static_cast<int64_t>(nq) * gx, 0, e->stream));

@@ -257,7 +257,8 @@ class Engine:
         """Counters of the two-stage dense search: searches served, overflow fallbacks, last candidate count."""
         out = {}
         for name, which in (("two_stage", 0), ("fallback", 1), ("last_candidates", 2), ("batched", 3),
-                            ("batch_fallback", 4), ("batch_candidates", 6)):
+                            ("batch_fallback", 4), ("batch_candidates", 6), ("sparse_grouped", 7),
+                            ("sparse_group_redo", 8), ("sparse_group_candidates", 9)):
             v = C.c_int64()
             check(self._lib.vr_stats(self._h, which, C.byref(v)))
             out[name] = int(v.value)
