@@ -270,7 +270,7 @@ int vr_delete_rows(vr_engine* e, const int64_t* rows, int64_t n);
 #define VR_STAT_BATCH_FALLBACK 4   /* ... of which exceeded their candidate budget and were redone alone */
 #define VR_STAT_BATCH_CANDIDATES 6 /* rows re-scored exactly by the batched search, summed over its queries */
 #define VR_STAT_SPARSE_GROUPED 7    /* sparse queries served by the grouped batch scan (groups of queries share a block per segment) */
-#define VR_STAT_SPARSE_GROUP_REDO 8 /* batches that scan gave up (candidate buffer overflow) and the per-query kernels redid */
+#define VR_STAT_SPARSE_GROUP_REDO 8 /* queries that scan gave up (a candidate region overflowed) and the per-query kernels redid */
 #define VR_STAT_SPARSE_GROUP_CANDIDATES 9 /* candidate keys the grouped scan's selections ranked (counted when the NEXT batch starts) */
 #define VR_STAT_GENERATION 5       /* bumped whenever row numbers change meaning (vr_compact, vr_load): a host
                                       table keyed by row is valid for the generation it was built against */

@@ -113,8 +113,9 @@ def test_grouped_sparse_batch_keeps_the_exact_answer(small, monkeypatch):
     queries share a block per segment, a term's postings are read once per group and added to every member's
     accumulators — in ascending term order per query, so the bits stay the forward scan's. Queries from a Zipfian
     vocabulary (shared common terms, the case it is built for), groups of 8 and of 4, a filter, k from 1 to 64; held
-    against the oracle and against the per-query kernels (VR_SPARSE_GROUPED=0). A candidate buffer too small for a
-    query (VR_SPARSE_GROUP_CAP) makes the engine redo the batch on the per-query kernels: same answer, counted."""
+    against the oracle and against the per-query kernels (VR_SPARSE_GROUPED=0). Candidates that do not fit
+    their (query, segment) region spill into the query's spill area (VR_SPARSE_GROUP_CAP); a spill area that overflows
+    (VR_SPARSE_GROUP_SPILL) makes the engine redo THAT query on the per-query kernels: same answer, counted."""
     from voitta_rag_amd import SearchFilter
 
     e, rng, x, sp, folder, live, vocab = small
@@ -152,13 +153,18 @@ def test_grouped_sparse_batch_keeps_the_exact_answer(small, monkeypatch):
     plain = e.search_sparse_batch(qs, 30)
     assert e.stats()["sparse_grouped"] == before["sparse_grouped"]
     monkeypatch.delenv("VR_SPARSE_GROUPED")
-    monkeypatch.setenv("VR_SPARSE_GROUP_CAP", "2")
+    monkeypatch.setenv("VR_SPARSE_GROUP_CAP", "2")     # two keys per (query, segment) region: the rest spills ...
+    before = e.stats()
+    spilled = e.search_sparse_batch(qs, 30)
+    assert e.stats()["sparse_group_redo"] == before["sparse_group_redo"]
+    monkeypatch.setenv("VR_SPARSE_GROUP_SPILL", "4")   # ... and a spill area of four keys overflows: those queries are redone
     before = e.stats()
     redone = e.search_sparse_batch(qs, 30)
-    assert e.stats()["sparse_group_redo"] == before["sparse_group_redo"] + 1
-    for a, b, c in zip(want, plain, redone):
+    assert e.stats()["sparse_group_redo"] > before["sparse_group_redo"]         # (counts the queries that were redone)
+    for a, b, c, d in zip(want, plain, redone, spilled):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
         assert np.array_equal(a[0], c[0]) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+        assert np.array_equal(a[0], d[0]) and np.array_equal(a[1].view(np.uint32), d[1].view(np.uint32))
 
 
 def test_sparse_batch_with_given_weights(small):

@@ -1071,16 +1071,35 @@ int sparse_batch_launch(vr_engine* e, const SparseBatch& b, int nq, int k, bool 
                              allow_grouped);
 }
 
-// After the stream of sparse_batch_launch has been synchronised: the grouped scan gives a batch up when a query's
-// candidate buffer overflows (invert.hip) — the batch is then repeated on the per-query kernels, whose answer does not
-// depend on any budget. Runs on e->stream and waits for it.
+// After the stream of sparse_batch_launch has been synchronised: the grouped scan gives up the queries whose candidate
+// regions overflowed (invert.hip) — those are repeated on the per-query kernels, whose answer does not depend on any
+// budget, and their rows of keys_host replaced. Runs on e->stream and waits for it.
 int sparse_batch_redo_if_overflowed(vr_engine* e, const SparseBatch& b, int nq, int k, bool weights_given, const uint8_t* mask,
                                     uint64_t* keys_host) {
-  if (*pin_host<int32_t>(e, kPinSparseOverflow) == 0) return 0;
-  e->stat_sparse_group_redo.fetch_add(1);
-  VR_TRY(sparse_batch_launch(e, b, nq, k, weights_given, mask, false));
-  VR_HIP(hipMemcpyAsync(keys_host, e->sq_keys.p, sizeof(uint64_t) * static_cast<size_t>(nq) * k, hipMemcpyDeviceToHost, e->stream));
+  if (*pin_host<int32_t>(e, kPinSparseOverflow) == 0 || !e->sq_overflow_q) return 0;
+  std::vector<int32_t> flagged(static_cast<size_t>(nq));
+  VR_HIP(hipMemcpyAsync(flagged.data(), e->sq_overflow_q, sizeof(int32_t) * static_cast<size_t>(nq), hipMemcpyDeviceToHost, e->stream));
   VR_HIP(hipStreamSynchronize(e->stream));
+  SparseBatch again;  // the same batch with the other queries' terms left out (an empty range: an empty list, at no cost)
+  again.off.assign(static_cast<size_t>(nq) + 1, 0);
+  int64_t n_again = 0;
+  for (int i = 0; i < nq; ++i) {
+    if (flagged[static_cast<size_t>(i)]) {
+      again.ids.insert(again.ids.end(), b.ids.begin() + b.off[static_cast<size_t>(i)], b.ids.begin() + b.off[static_cast<size_t>(i) + 1]);
+      again.vals.insert(again.vals.end(), b.vals.begin() + b.off[static_cast<size_t>(i)], b.vals.begin() + b.off[static_cast<size_t>(i) + 1]);
+      ++n_again;
+    }
+    again.off[static_cast<size_t>(i) + 1] = static_cast<int32_t>(again.ids.size());
+  }
+  e->stat_sparse_group_redo.fetch_add(n_again);
+  if (n_again == 0) return 0;
+  VR_TRY(sparse_batch_launch(e, again, nq, k, weights_given, mask, false));
+  std::vector<uint64_t> keys(static_cast<size_t>(nq) * k);
+  VR_HIP(hipMemcpyAsync(keys.data(), e->sq_keys.p, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost, e->stream));
+  VR_HIP(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < nq; ++i)
+    if (flagged[static_cast<size_t>(i)])
+      memcpy(keys_host + static_cast<size_t>(i) * k, keys.data() + static_cast<size_t>(i) * k, sizeof(uint64_t) * static_cast<size_t>(k));
   return 0;
 }
 

@@ -205,7 +205,7 @@ struct vr_engine {
   std::atomic<int64_t> stat_last_candidates{0}; // rows re-scored by the last two-stage search
   std::atomic<int64_t> stat_sparse_grouped{0};    // sparse queries served by the grouped batch scan (invert.hip)
   std::atomic<int64_t> stat_sparse_group_cands{0}; // candidate keys its selection ranked (read when the next batch starts)
-  std::atomic<int64_t> stat_sparse_group_redo{0}; // batches it gave up (a candidate buffer overflowed) and the per-query kernels redid
+  std::atomic<int64_t> stat_sparse_group_redo{0}; // queries it gave up (a candidate region overflowed) and the per-query kernels redid
   std::atomic<int64_t> generation{0};           // bumped whenever row numbers change (vr_compact's swap, vr_load)
   vr::DevArray<uint16_t> corpus16;
   vr::DevArray<float> row_err;
@@ -290,6 +290,7 @@ struct vr_engine {
   vr::DevArray<uint64_t> sq_keys;
   // ... grouped form (sparse_inv_group_kernel): the group tables, per query a candidate buffer and its fill count
   vr::DevArray<int32_t> sq_grp, sq_cnt;
+  const int32_t* sq_overflow_q = nullptr;  // (into sq_cnt) per query of the last grouped batch: 1 = its candidates overflowed
   vr::DevArray<uint64_t> sq_cand;   // (+ the groups' threshold keys behind the buffers)
   vr::DevArray<int32_t> sq_bounds;  // int2 run bounds per (segment, distinct term), then per (segment, group, union term)
   vr::DevArray<float> sq_entw;      // weights per (group, union term, query of the group)
@@ -368,11 +369,13 @@ int topk_select(vr_engine* e, const float* scores, int64_t stride, int64_t n, in
 // fused scan kernels); writes the k best of every query to out ([nq][k], descending; device-
 // visible memory, normally the pinned result area so that no copy follows).
 int topk_merge_lists(vr_engine* e, uint64_t* cand, int n_lists, int nq, int k, uint64_t* out);  // clobbers cand
-// per query the k best keys of its n_reg regions cand[q][r][cap], region r holding min(cnt[q][r], cap) keys (unsorted,
-// unique); *overflow_mapped (device view of a pinned word) is set to 1 when a region was offered more than cap keys or a
-// query holds more than 4096 in all; *total_mapped (may be null) += the keys gathered
-int topk_select_regions(vr_engine* e, const uint64_t* cand, int n_reg, int cap, const int32_t* cnt, int nq, int k, uint64_t* out,
-                        int32_t* overflow_mapped, int32_t* total_mapped);
+// per query the k best keys of its n_reg regions cand[q][r][cap] (region r holding min(cnt[q][r], cap) keys, unsorted,
+// unique) and of its spill area spill[q][spill_cap] (spill_cnt[q] keys were offered to it; spill may be null);
+// *overflow_mapped (device view of a pinned word) is set to 1, and overflow_q[q] (may be null; zeroed by the caller), when a
+// query's spill area overflowed or it holds more than 8192 keys in all; *total_dev (may be null) += the keys gathered
+int topk_select_regions(vr_engine* e, const uint64_t* cand, int n_reg, int cap, const int32_t* cnt, const uint64_t* spill,
+                        int spill_cap, const int32_t* spill_cnt, int nq, int k, uint64_t* out, int32_t* overflow_mapped,
+                        int32_t* total_dev, int32_t* overflow_q);
 // fused scan + selection, k <= kFusedMaxK; results to out_keys_dev as above
 int dense_scan_topk(vr_engine* e, int nq, int k, const uint8_t* mask_dev, uint64_t* out_keys_dev);
 int sparse_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_host, int nnz, int k,
@@ -407,8 +410,8 @@ int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
 // q_val_dev; q_w_dev: room for 2 x n_terms floats — the weights, then the terms' df shares); nq x k keys to out_keys_dev
 // q_off_host / q_ids_host: the same CSR on the host (the grouped scan builds its group tables from it; nullptr or
 // allow_grouped = false: the per-query kernels). The grouped scan may give up on a batch (a candidate buffer overflowed):
-// it then leaves 1 in the pinned word kPinSparseOverflow, to be read once the stream has been synchronised — the caller
-// repeats the call with allow_grouped = false.
+// it then leaves 1 in the pinned word kPinSparseOverflow, to be read once the stream has been synchronised, and 1 per
+// overflowed query in e->sq_overflow_q (device) — the caller repeats THOSE queries with allow_grouped = false.
 int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q_ids_dev, const float* q_val_dev,
                         float* q_w_dev, int nq, int n_terms, bool weights_given, float n_points, const uint8_t* mask_dev,
                         int k, uint64_t* out_keys_dev, const int32_t* q_off_host = nullptr,

@@ -1264,7 +1264,8 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
     const InvSeg* __restrict__ segs, const uint64_t* __restrict__ keys, const float* __restrict__ vals,
     const int32_t* __restrict__ grp_hdr, const int32_t* __restrict__ grp_ent, const float* __restrict__ ent_w,
     const int2* __restrict__ bounds, int stride_u, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ theta,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ cnt, int cap, int dbg_mode, int seg_stride) {
+    uint64_t* __restrict__ cand, int32_t* __restrict__ cnt, int cap, int dbg_mode, int seg_stride,
+    uint64_t* __restrict__ spill, int32_t* __restrict__ spill_cnt, int spill_cap, int sample_tail, int n_seg_all) {
   static_assert(G >= 1 && G <= 8, "group size");
   __shared__ __align__(16) float acc[G * kInvSegRows];
   __shared__ int32_t s_mask[kGrpMaxU];         // by compacted run: the queries that carry its term
@@ -1277,7 +1278,12 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
   __shared__ int32_t s_cnt[G];
   const int tid = threadIdx.x, lane = tid & 63;
   const int grp = blockIdx.x;
-  const int seg_no = SAMPLE ? static_cast<int>(blockIdx.y) * seg_stride : static_cast<int>(blockIdx.y);
+  // (SAMPLE: every seg_stride-th segment, then the last sample_tail segments — the rows stored last often differ from
+  // the bulk, and a threshold that has not seen them lets all of them through)
+  const int n_regular = static_cast<int>(gridDim.y) - sample_tail;
+  const int seg_no = !SAMPLE ? static_cast<int>(blockIdx.y)
+                             : static_cast<int>(blockIdx.y) < n_regular ? static_cast<int>(blockIdx.y) * seg_stride
+                                                                        : n_seg_all - (static_cast<int>(gridDim.y) - static_cast<int>(blockIdx.y));
   const InvSeg seg = segs[seg_no];
   const int64_t gu0 = static_cast<int64_t>(grp) * stride_u;
   // the filter bytes of the 8 rows this thread will look at when the sums are complete (rows past the segment: 0)
@@ -1473,7 +1479,12 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
           best = key > best ? key : best;
         } else {
           const int slot = atomicAdd(&s_cnt[g], 1);
-          if (slot < cap) region[slot] = key;
+          if (slot < cap) {
+            region[slot] = key;
+          } else {  // (rare: the candidates of a query crowd into one segment) the query's spill area, a global counter
+            const int at = atomicAdd(&spill_cnt[q], 1);
+            if (at < spill_cap) spill[static_cast<int64_t>(q) * spill_cap + at] = key;
+          }
         }
       }
       if (SAMPLE) {  // the wave's best key (cap >= 8: one slot per wave)
@@ -1639,13 +1650,17 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   const int64_t n_gu = static_cast<int64_t>(lay.n_groups) * lay.stride_u;
   // the sample: every seg_stride-th segment, 8 keys (one per wave of the block) per (query, sampled segment)
   const int seg_stride = sampled ? static_cast<int>(n_seg / 16) : 1;
-  const int64_t n_samp = sampled ? (n_seg + seg_stride - 1) / seg_stride : 0;
+  constexpr int kSampleTail = 4;  // ... and the last segments (the rows stored last)
+  const int64_t n_samp = sampled ? (n_seg - kSampleTail + seg_stride - 1) / seg_stride + kSampleTail : 0;
   constexpr int kSampCap = kGrpThreads / 64;
   const int64_t cand_main = static_cast<int64_t>(nq) * n_seg * cand_cap, cand_samp = static_cast<int64_t>(nq) * n_samp * kSampCap;
-  const int64_t cnt_main = static_cast<int64_t>(nq) * n_seg + 1, cnt_samp = static_cast<int64_t>(nq) * n_samp;  // (+ the keys ranked)
+  // (+ the keys ranked, + a flag per query whose candidates overflowed, + the fill of its spill area)
+  const int64_t cnt_main = static_cast<int64_t>(nq) * n_seg + 1 + 2 * static_cast<int64_t>(nq), cnt_samp = static_cast<int64_t>(nq) * n_samp;
+  // keys per query that did not fit their (query, segment) region (VR_SPARSE_GROUP_SPILL: tests shrink it to force the redo)
+  const int kSpillCap = std::getenv("VR_SPARSE_GROUP_SPILL") ? std::min(4096, std::max(1, atoi(std::getenv("VR_SPARSE_GROUP_SPILL")))) : 4096;
   VR_TRY(e->sq_grp.grow(static_cast<int64_t>(e->sq_grp_host.size()), 0, e->stream));
   VR_TRY(e->sq_cnt.grow(cnt_main + cnt_samp, 0, e->stream));
-  VR_TRY(e->sq_cand.grow(cand_main + cand_samp + static_cast<int64_t>(lay.n_groups) * 8, 0, e->stream));
+  VR_TRY(e->sq_cand.grow(cand_main + cand_samp + static_cast<int64_t>(lay.n_groups) * 8 + static_cast<int64_t>(nq) * kSpillCap, 0, e->stream));
   // run bounds per (segment, distinct term), then per (segment, group, union term); the weights per (group, union term, query)
   VR_TRY(e->sq_bounds.grow(2 * (n_seg * lay.n_slots + n_seg * n_gu), 0, e->stream));
   VR_TRY(e->sq_entw.grow(n_gu * 8, 0, e->stream));
@@ -1653,7 +1668,11 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   int2* grp_bounds = slot_bounds + n_seg * lay.n_slots;
   uint64_t* samp_cand = e->sq_cand.p + cand_main;
   uint64_t* theta = samp_cand + cand_samp;
+  uint64_t* spill = theta + static_cast<int64_t>(lay.n_groups) * 8;
   int32_t* samp_cnt = e->sq_cnt.p + cnt_main;
+  int32_t* ranked = e->sq_cnt.p + static_cast<int64_t>(nq) * n_seg;
+  int32_t* overflow_q = ranked + 1;
+  int32_t* spill_cnt = overflow_q + nq;
   const int32_t* hdr = e->sq_grp.p;
   const int32_t* ent = e->sq_grp.p + lay.ent_off;
   VR_HIP(hipMemcpyAsync(e->sq_grp.p, e->sq_grp_host.data(), sizeof(int32_t) * e->sq_grp_host.size(), hipMemcpyHostToDevice, e->stream));
@@ -1668,7 +1687,7 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   auto launch = [&](auto kernel, int64_t rows_y, uint64_t* cand, int32_t* cnt, int cap, int stride) {
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(lay.n_groups), static_cast<unsigned>(rows_y)), dim3(kGrpThreads), 0, e->stream,
                        e->inv_seg.p, e->inv_key.p, e->inv_val.p, hdr, ent, e->sq_entw.p, grp_bounds, lay.stride_u, mask_dev, theta, cand,
-                       cnt, cap, dbg_mode, stride);
+                       cnt, cap, dbg_mode, stride, spill, spill_cnt, kSpillCap, kSampleTail, static_cast<int>(n_seg));
   };
   if (sampled) {
     // thresholds: the sampled segments scanned in full, the best key of every 512 rows kept; the k-th best of a query's
@@ -1676,8 +1695,8 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
     if (group_size == 2) launch(sparse_inv_group_kernel<2, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
     else if (group_size == 4) launch(sparse_inv_group_kernel<4, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
     else launch(sparse_inv_group_kernel<8, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
-    VR_TRY(topk_select_regions(e, samp_cand, static_cast<int>(n_samp), kSampCap, samp_cnt, nq, k, out_keys_dev,
-                               pin_dev<int32_t>(e, kPinSparseOverflow), nullptr));
+    VR_TRY(topk_select_regions(e, samp_cand, static_cast<int>(n_samp), kSampCap, samp_cnt, nullptr, 0, nullptr, nq, k, out_keys_dev,
+                               pin_dev<int32_t>(e, kPinSparseOverflow), nullptr, nullptr));
   }
   hipLaunchKernelGGL(sparse_inv_theta_kernel, dim3(static_cast<unsigned>((lay.n_groups * 8 + 255) / 256)), dim3(256), 0, e->stream, hdr,
                      lay.n_groups, out_keys_dev, k, theta);
@@ -1687,9 +1706,40 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   prof_end(e);
   VR_HIP(hipGetLastError());
   e->stat_sparse_grouped += nq;
-  int32_t* ranked = e->sq_cnt.p + cnt_main - 1;
-  VR_TRY(topk_select_regions(e, e->sq_cand.p, static_cast<int>(n_seg), cand_cap, e->sq_cnt.p, nq, k, out_keys_dev,
-                             pin_dev<int32_t>(e, kPinSparseOverflow), ranked));
+  e->sq_overflow_q = overflow_q;
+  VR_TRY(topk_select_regions(e, e->sq_cand.p, static_cast<int>(n_seg), cand_cap, e->sq_cnt.p, spill, kSpillCap, spill_cnt, nq, k,
+                             out_keys_dev, pin_dev<int32_t>(e, kPinSparseOverflow), ranked, overflow_q));
+  if (std::getenv("VR_SPARSE_GROUP_DEBUG") && atoi(std::getenv("VR_SPARSE_GROUP_DEBUG")) != 0) {  // diagnostics: what filled the regions
+    std::vector<int32_t> h(static_cast<size_t>(cnt_main));
+    std::vector<uint64_t> th(static_cast<size_t>(lay.n_groups) * 8);
+    VR_HIP(hipMemcpyAsync(h.data(), e->sq_cnt.p, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipMemcpyAsync(th.data(), theta, sizeof(uint64_t) * th.size(), hipMemcpyDeviceToHost, e->stream));
+    VR_HIP(hipStreamSynchronize(e->stream));
+    int64_t over_regions = 0, max_region = 0, max_total = 0, over_q = 0, no_theta = 0, n_members = 0, max_spill = 0;
+    int worst_q = -1, worst_seg = -1;
+    for (int q = 0; q < nq; ++q) {
+      int64_t tot = 0;
+      for (int64_t s2 = 0; s2 < n_seg; ++s2) {
+        const int32_t c = h[static_cast<size_t>(q * n_seg + s2)];
+        tot += c;
+        over_regions += c > cand_cap;
+        if (c > max_region) max_region = c, worst_q = q, worst_seg = static_cast<int>(s2);
+      }
+      max_total = std::max(max_total, tot);
+      over_q += h[static_cast<size_t>(nq) * n_seg + 1 + q];
+      max_spill = std::max<int64_t>(max_spill, h[static_cast<size_t>(nq) * n_seg + 1 + nq + q]);
+    }
+    for (size_t i = 0; i < th.size(); ++i)
+      if (th[i] != ~0ull) {
+        ++n_members;
+        no_theta += th[i] == 0ull;
+      }
+    fprintf(stderr, "[sparse grouped] %d queries (%lld in groups, %lld without a threshold), %lld segments, region cap %d: largest region %lld "
+            "(query %d, segment %d), %lld regions over the cap, largest query total %lld, largest spill %lld, %lld queries overflowed\n", nq,
+            static_cast<long long>(n_members), static_cast<long long>(no_theta), static_cast<long long>(n_seg), cand_cap,
+            static_cast<long long>(max_region), worst_q, worst_seg, static_cast<long long>(over_regions),
+            static_cast<long long>(max_total), static_cast<long long>(max_spill), static_cast<long long>(over_q));
+  }
   VR_HIP(hipMemcpyAsync(pin_host<int32_t>(e, kPinSparseCands), ranked, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   return 0;
 }

@@ -99,26 +99,32 @@ __global__ __launch_bounds__(THREADS) void select_from_keys_kernel(const uint64_
   block_extract_topk<THREADS, ITEMS>(keys, k, out + (static_cast<int64_t>(q) * gridDim.x + seg) * k);
 }
 
-// keys [nq][n_reg][cap]: region r of query q holds min(cnt[q][r], cap) real keys (unsorted, unique) -> keys [nq][k].
-// A region that was offered more than cap keys, or a query with more than THREADS * ITEMS keys in all, sets *overflow.
+// keys [nq][n_reg][cap]: region r of query q holds min(cnt[q][r], cap) real keys (unsorted, unique); what a full region
+// could not take went to the query's spill area spill[q][spill_cap] (spill_cnt[q] keys were offered to it; may be null)
+// -> keys [nq][k]. A query whose spill area overflowed, or with more than THREADS * ITEMS keys in all, sets *overflow and
+// overflow_q[q].
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void select_regions_kernel(const uint64_t* __restrict__ in, int n_reg, int cap,
-                                                                 const int32_t* __restrict__ cnt, int k,
+                                                                 const int32_t* __restrict__ cnt,
+                                                                 const uint64_t* __restrict__ spill, int spill_cap,
+                                                                 const int32_t* __restrict__ spill_cnt, int k,
                                                                  uint64_t* __restrict__ out,
                                                                  int32_t* __restrict__ overflow,
-                                                                 int32_t* __restrict__ total_out) {
+                                                                 int32_t* __restrict__ total_out,
+                                                                 int32_t* __restrict__ overflow_q) {
   __shared__ uint64_t gat[THREADS * ITEMS];
   __shared__ int n_gat;
   const int q = blockIdx.x;
-  if (threadIdx.x == 0) n_gat = 0;
+  const int n_spill = spill_cnt ? spill_cnt[q] : 0;
+  if (threadIdx.x == 0) n_gat = n_spill < spill_cap ? n_spill : spill_cap;
   __syncthreads();
+  for (int j = threadIdx.x; j < n_spill && j < spill_cap; j += THREADS)
+    if (j < THREADS * ITEMS) gat[j] = spill[static_cast<int64_t>(q) * spill_cap + j];
   const uint64_t* base = in + static_cast<int64_t>(q) * n_reg * cap;
   const int32_t* c = cnt + static_cast<int64_t>(q) * n_reg;
-  bool over = false;
   for (int r = threadIdx.x; r < n_reg; r += THREADS) {
     const int have = c[r];
     if (have <= 0) continue;
-    over |= have > cap;
     const int n = have < cap ? have : cap;
     const int at = atomicAdd(&n_gat, n);
     for (int j = 0; j < n; ++j)
@@ -126,8 +132,13 @@ __global__ __launch_bounds__(THREADS) void select_regions_kernel(const uint64_t*
   }
   __syncthreads();
   const int total = n_gat;
-  if (threadIdx.x == 0 && total_out) atomicAdd(total_out, total);
-  if (over || (threadIdx.x == 0 && total > THREADS * ITEMS)) *overflow = 1;
+  if (threadIdx.x == 0) {
+    if (total_out) atomicAdd(total_out, total);
+    if (n_spill > spill_cap || total > THREADS * ITEMS) {
+      *overflow = 1;
+      if (overflow_q) overflow_q[q] = 1;
+    }
+  }
   uint64_t keys[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -137,11 +148,12 @@ __global__ __launch_bounds__(THREADS) void select_regions_kernel(const uint64_t*
   block_extract_topk<THREADS, ITEMS>(keys, k, out + static_cast<int64_t>(q) * k);
 }
 
-int topk_select_regions(vr_engine* e, const uint64_t* cand, int n_reg, int cap, const int32_t* cnt, int nq, int k, uint64_t* out,
-                        int32_t* overflow_mapped, int32_t* total_mapped) {
+int topk_select_regions(vr_engine* e, const uint64_t* cand, int n_reg, int cap, const int32_t* cnt, const uint64_t* spill,
+                        int spill_cap, const int32_t* spill_cnt, int nq, int k, uint64_t* out, int32_t* overflow_mapped,
+                        int32_t* total_dev, int32_t* overflow_q) {
   VR_CHECK(k >= 1 && k <= kMaxK && nq >= 1 && cap >= 1 && n_reg >= 1, "bad region-select shape");
-  hipLaunchKernelGGL((select_regions_kernel<1024, 4>), dim3(static_cast<unsigned>(nq)), dim3(1024), 0, e->stream, cand, n_reg, cap,
-                     cnt, k, out, overflow_mapped, total_mapped);
+  hipLaunchKernelGGL((select_regions_kernel<1024, 8>), dim3(static_cast<unsigned>(nq)), dim3(1024), 0, e->stream, cand, n_reg, cap,
+                     cnt, spill, spill_cap, spill_cnt, k, out, overflow_mapped, total_dev, overflow_q);
   VR_HIP(hipGetLastError());
   return 0;
 }
