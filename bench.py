@@ -714,16 +714,25 @@ def main():
         sq_list = (sq_off, np.concatenate([q[0] for q in sq_list]).astype(np.int32), np.ones(int(sq_off[-1]), np.float32))
     hyb_call = ((lambda: searcher.search_hybrid_batch(qb, sq_list, 10, 0.1)) if world > 1
                 else (lambda: engine.search_hybrid_batch(qb, sq_list, 10, 0.1, raw=True)))
-    hyb_batched, hyb_dt, recall_hybrid = None, float("nan"), None
+    hyb_batched, hyb_dt, recall_hybrid, hyb_sparse = None, float("nan"), None, None
     try:
         for _ in range(2):
             hyb_batched = hyb_call()
         barrier()
+        st0 = engine.stats()
         t1 = time.perf_counter()
         for _ in range(batch_reps):
             hyb_batched = hyb_call()
         barrier()
         hyb_dt = time.perf_counter() - t1
+        st1 = engine.stats()
+        n_grouped = st1.get("sparse_grouped", 0) - st0.get("sparse_grouped", 0)
+        # (the candidate count of a call is booked when the next one starts: the timed calls' counts are those of
+        # batch_reps calls, shifted by one)
+        hyb_sparse = {"queries_through_the_grouped_scan": n_grouped,
+                      "queries_redone_on_the_per_query_kernels": st1.get("sparse_group_redo", 0) - st0.get("sparse_group_redo", 0),
+                      "candidate_keys_ranked_per_query": round((st1.get("sparse_group_candidates", 0) - st0.get("sparse_group_candidates", 0))
+                                                               / max(n_grouped, 1), 1)}
         # recall@10 against the single-query hybrid path (itself held to the oracle bit for bit by the tests)
         hits, n_ref = 0, min(100, args.queries)
         for i in range(n_ref):
@@ -860,9 +869,11 @@ def main():
             "qps_hybrid_batched_1k": None if qps_hybrid is None else round(qps_hybrid, 1),
             "ms_per_hybrid_batched_call": None if qps_hybrid is None else round(hyb_dt / batch_reps * 1e3, 3),
             "hybrid_batched_kind": f"{args.queries} hybrid top-10 queries per call (vr_search_hybrid_batch: one batched dense search, one "
-                                   "batched sparse search over the inverted index beside it, min-max fusion of every query on the host "
-                                   "threads; host arrays in and out); answers bit-identical to the single-query path "
-                                   "(tests/test_batch_hybrid_gpu.py, tests/test_fullsize_gpu.py)",
+                                   "batched sparse search over the inverted index beside it — the grouped scan of csrc/invert.hip: "
+                                   "groups of four queries share a block per segment, thresholds from a sample of the segments — "
+                                   "min-max fusion of every query on the host threads; host arrays in and out); answers "
+                                   "bit-identical to the single-query path (tests/test_batch_hybrid_gpu.py, tests/test_fullsize_gpu.py)",
+            "hybrid_batched_sparse_leg": hyb_sparse,
             "recall_at_10_hybrid_batched_vs_single_query": recall_hybrid,
             "other_model_widths": other,
             "recall_at_10_batched_vs_torch_matmul": recall_batched,
