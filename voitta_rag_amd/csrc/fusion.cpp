@@ -77,7 +77,8 @@ struct Cand {
 void normalize(const float* scores, int n, int json_scores, std::vector<double>* out) {
   out->assign(static_cast<size_t>(n), 0.0);
   if (n == 0) return;
-  std::vector<double> v(static_cast<size_t>(n));
+  static thread_local std::vector<double> v;  // (scratch kept per thread: no allocation per query)
+  v.resize(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) v[static_cast<size_t>(i)] = to_python_float(scores[i], json_scores);
   double mn = v[0], mx = v[0];
   for (double x : v) {
@@ -107,9 +108,33 @@ int emit(std::vector<Cand>& all, int limit, int64_t* out_rows, double* out_score
 
 void gather(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, std::vector<Cand>* all,
             std::vector<int>* d_pos, std::vector<int>* s_pos) {
-  std::unordered_map<int64_t, int> at;
   d_pos->resize(static_cast<size_t>(nd));
   s_pos->resize(static_cast<size_t>(ns));
+  all->reserve(static_cast<size_t>(nd + ns));
+  if (nd + ns <= 128) {
+    // the usual case (two lists of 3 x limit ids): an open-addressing table on the stack instead of a node-based map
+    // (a batched hybrid search fuses a thousand queries on the host threads: the map's allocations were a third of it)
+    constexpr int kSlots = 512;
+    int64_t key[kSlots];
+    int16_t at[kSlots];
+    for (int i = 0; i < kSlots; ++i) at[i] = -1;
+    auto slot = [&](int64_t row) {
+      uint32_t h = static_cast<uint32_t>((static_cast<uint64_t>(row) * 0x9E3779B97F4A7C15ull) >> 55);  // 9 bits
+      while (at[h] >= 0 && key[h] != row) h = (h + 1) & (kSlots - 1);
+      if (at[h] < 0) {
+        key[h] = row;
+        at[h] = static_cast<int16_t>(all->size());
+        Cand c;
+        c.row = row;
+        all->push_back(c);
+      }
+      return static_cast<int>(at[h]);
+    };
+    for (int i = 0; i < nd; ++i) (*d_pos)[static_cast<size_t>(i)] = slot(d_rows[i]);
+    for (int i = 0; i < ns; ++i) (*s_pos)[static_cast<size_t>(i)] = slot(s_rows[i]);
+    return;
+  }
+  std::unordered_map<int64_t, int> at;
   auto slot = [&](int64_t row) {
     auto it = at.find(row);
     if (it != at.end()) return it->second;
@@ -129,11 +154,12 @@ int fuse_minmax(const int64_t* d_rows, const float* d_scores, int nd, const int6
                 const float* s_scores, int ns, int limit, double sparse_weight, int json_scores,
                 int64_t* out_rows, double* out_scores, int32_t* out_from_dense, int32_t* out_count) {
   const double dense_weight = 1.0 - sparse_weight;  // vector_store.py:634
-  std::vector<double> dn, sn;
+  static thread_local std::vector<double> dn, sn;
   normalize(d_scores, nd, json_scores, &dn);
   normalize(s_scores, ns, json_scores, &sn);
-  std::vector<Cand> all;
-  std::vector<int> dp, sp;
+  static thread_local std::vector<Cand> all;
+  static thread_local std::vector<int> dp, sp;
+  all.clear();
   gather(d_rows, nd, s_rows, ns, &all, &dp, &sp);
   // a later duplicate of an id overwrites the earlier one, as the dict assignment at :668 does
   for (int i = 0; i < nd; ++i) {
@@ -162,8 +188,9 @@ int fuse_minmax(const int64_t* d_rows, const float* d_scores, int nd, const int6
 int fuse_rrf(const int64_t* d_rows, int nd, const int64_t* s_rows, int ns, int limit,
              double /*sparse_weight*/, int64_t* out_rows, double* out_scores,
              int32_t* out_from_dense, int32_t* out_count) {
-  std::vector<Cand> all;
-  std::vector<int> dp, sp;
+  static thread_local std::vector<Cand> all;
+  static thread_local std::vector<int> dp, sp;
+  all.clear();
   gather(d_rows, nd, s_rows, ns, &all, &dp, &sp);
   for (int i = 0; i < nd; ++i) {
     Cand& c = all[static_cast<size_t>(dp[static_cast<size_t>(i)])];
