@@ -147,6 +147,20 @@ def test_grouped_sparse_batch_keeps_the_exact_answer(small, monkeypatch):
                     assert np.array_equal(got[i][0], wr), (group, k, i)
                     assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), (group, k, i)
     monkeypatch.delenv("VR_SPARSE_GROUP")
+    # long queries: 24-32 terms each, so a group's union of terms passes the 64 the scan block holds and the host has to
+    # close groups early (down to one query per group); weights with both signs (sums that cancel, negative scores)
+    long_qs = []
+    for i in range(40):
+        m = int(rng.integers(24, 33))
+        ids = rng.choice(by_df, size=m, replace=False, p=p).astype(np.int32)
+        long_qs.append((ids, rng.uniform(-1.0, 1.5, size=m).astype(np.float32)))
+    before = e.stats()
+    got = e.search_sparse_batch(long_qs, 30)
+    assert e.stats()["sparse_grouped"] - before["sparse_grouped"] == len(long_qs)
+    for i, (qi, qv) in enumerate(long_qs):
+        wr, ws = ocore.topk(sp.scores(qi, qv), 30, live)
+        assert np.array_equal(got[i][0], wr), i
+        assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), i
     want = e.search_sparse_batch(qs, 30)
     monkeypatch.setenv("VR_SPARSE_GROUPED", "0")
     before = e.stats()
