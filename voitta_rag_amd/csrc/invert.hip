@@ -1467,6 +1467,14 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
       const uint32_t th_hi = static_cast<uint32_t>(th >> 32);
       uint64_t* region = cand + (static_cast<int64_t>(q) * gridDim.y + blockIdx.y) * cap;
       uint64_t best = 0ull;
+      if (!SAMPLE && th_hi >= 0x80000000u) {
+        // a threshold >= +0.0 (BM25 scores are positive): a row reaches it iff its score's bits, read as a signed integer,
+        // reach the threshold's (negative scores and the untouched pattern are negative integers) — the largest of the
+        // eight settles nearly every thread in four instructions (the kernel is bound by its instruction count)
+        const int m = max(max(max(static_cast<int>(sc[g][0]), static_cast<int>(sc[g][1])), max(static_cast<int>(sc[g][2]), static_cast<int>(sc[g][3]))),
+                          max(max(static_cast<int>(sc[g][4]), static_cast<int>(sc[g][5])), max(static_cast<int>(sc[g][6]), static_cast<int>(sc[g][7]))));
+        if (m < static_cast<int>(th_hi & 0x7FFFFFFFu)) continue;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t bits = sc[g][j];
