@@ -772,17 +772,37 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 // drained. The two legs share nothing but the mask: the (small, latency-bound) sparse leg is forked onto the auxiliary
 // stream and runs under the dense scan. The k > kFusedMaxK sparse path borrows the dense leg's selection buffers and
 // stays on the main stream.
+// The sparse leg of a hybrid query queued on the lane's auxiliary stream right away (behind the mask on the main
+// stream): what vr_query_text does BEFORE the question's forward pass — the leg needs the words, not the embedding,
+// and its kernel (tens to hundreds of microseconds when the words are common ones) then runs under the encoder
+// instead of beside the dense scan. hybrid_one_query(..., sparse_in_flight = true) joins it.
+static int hybrid_sparse_ahead(vr_engine* e, const int32_t* q_idx, const float* q_val, int nnz, int k, const uint8_t* mask,
+                               bool weights_given) {
+  VR_CHECK(q_idx && q_val && nnz > 0 && k <= kFusedMaxK && e->n_slices_dev > 0, "no sparse leg to start ahead");
+  VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask
+  VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+  hipStream_t main_stream = e->stream;
+  e->stream = e->aux_stream;
+  const int rc = search_sparse_block(e, q_idx, q_val, nnz, k, mask, weights_given);
+  e->stream = main_stream;
+  if (rc != 0) return rc;
+  VR_HIP(hipEventRecord(e->ev_join, e->aux_stream));
+  return 0;
+}
+
 static int hybrid_one_query(vr_engine* e, const float* q, int mem, const int32_t* q_idx, const float* q_val, int nnz, int k,
-                            bool weights_given, const uint8_t* mask, bool* have_sparse_out) {
+                            bool weights_given, const uint8_t* mask, bool* have_sparse_out, bool sparse_in_flight = false) {
   const float* q_dev = stage_query(e, q, 1, mem);
   bool two_stage = false;
   const bool have_sparse = nnz > 0 && e->n_slices_dev > 0;
   *have_sparse_out = have_sparse;
-  const bool fork = have_sparse && k <= kFusedMaxK;
+  const bool fork = have_sparse && k <= kFusedMaxK && !sparse_in_flight;
   if (have_sparse) VR_CHECK(q_idx && q_val, "null sparse query");
   if (fork) VR_HIP(hipEventRecord(e->ev_fork, e->stream));  // after the mask, before the dense leg
   VR_TRY(search_dense_block(e, q_dev, 1, k, mask, true, &two_stage));
-  if (fork) {
+  if (sparse_in_flight) {
+    VR_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  } else if (fork) {
     // queued after the dense leg (whose scan is already running by now), executed beside it
     VR_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
     hipStream_t main_stream = e->stream;
@@ -1452,18 +1472,42 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
     float* p;
     ~Giver() { give_query_row(device, p); }
   } giver{e->device, q_dev};
-  {
-    const int32_t off32[2] = {0, static_cast<int32_t>(wp_off[1])};
-    std::lock_guard<std::mutex> writer(e->wmu);
-    VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
-  }
-  // 3. the search, on a lane
+  const int32_t off32[2] = {0, static_cast<int32_t>(wp_off[1])};
   const bool hybrid = !stems.empty();
   if (out_hybrid) *out_hybrid = hybrid ? 1 : 0;
   if (hybrid) {
+    // 3a. hybrid: the lane is taken first and the SPARSE leg started on its auxiliary stream — it needs the words, not
+    //     the embedding, and with common words its kernel is as long as the dense scan — then the forward pass, then
+    //     the dense leg; the sparse leg has run under the encoder by then. Lock order as everywhere: the writers'
+    //     mutex (the encoder), then the shared lock of the lane — a writer takes the same mutex before it publishes.
+    const int k = limit * 3;  // prefetch_limit, vector_store.py:636
     std::vector<float> ones(stems.size(), 1.0f);
-    return vr_search_hybrid(e, q_dev, VR_MEM_DEVICE, stems.data(), ones.data(), static_cast<int32_t>(stems.size()), limit,
-                            sparse_weight, fusion, filter, out_rows, out_scores, out_from_dense, out_count);
+    std::unique_lock<std::mutex> writer(e->wmu);
+    SearchLane lane(e);
+    VR_TRY(lane.acquire(false));
+    vr_engine* L = lane.L;
+    if (L->n_rows == 0) return 0;
+    const uint8_t* mask = nullptr;
+    VR_TRY(filter_build_mask(L, filter, &mask));
+    const int nnz = static_cast<int>(stems.size());
+    const bool ahead = L->n_slices_dev > 0 && k <= kFusedMaxK;
+    if (ahead) VR_TRY(hybrid_sparse_ahead(L, stems.data(), ones.data(), nnz, k, mask, false));
+    VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
+    writer.unlock();
+    bool have_sparse = false;
+    VR_TRY(hybrid_one_query(L, q_dev, VR_MEM_DEVICE, stems.data(), ones.data(), nnz, k, false, mask, &have_sparse, ahead));
+    int64_t d_rows[kMaxK], s_rows[kMaxK];
+    float d_scores[kMaxK], s_scores[kMaxK];
+    const int nd = static_cast<int>(decode_keys(pin_host<uint64_t>(L, kPinDenseKeys), k, d_rows, d_scores));
+    const int ns = have_sparse ? static_cast<int>(decode_keys(pin_host<uint64_t>(L, kPinSparseKeys), k, s_rows, s_scores)) : 0;
+    if (fusion == VR_FUSION_MINMAX)
+      return fuse_minmax(d_rows, d_scores, nd, s_rows, s_scores, ns, limit, sparse_weight, 1, out_rows, out_scores, out_from_dense,
+                         out_count);
+    return fuse_rrf(d_rows, nd, s_rows, ns, limit, sparse_weight, out_rows, out_scores, out_from_dense, out_count);
+  }
+  {
+    std::lock_guard<std::mutex> writer(e->wmu);
+    VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
   }
   // no term survived the stop-word filter: the dense-only branch of VectorStoreService.search (vector_store.py:612-617)
   std::vector<float> sc(static_cast<size_t>(limit));
