@@ -1,4 +1,7 @@
 #!/bin/bash
+# The grouped sparse batch scan (csrc/invert.hip) on the GPU box: its parity tests (incl. the 1.25M-row configs[4] share), the
+# timings of scripts/perf_hybrid_batch.py, the seed-pass variant, and the time split with parts of the scan switched off
+# (VR_SPARSE_GROUP_DBG; profiles/r03_experiments.md §12). Outputs under gpurun_out/grp/.
 set -o pipefail
 R=/root/repo; O=$R/gpurun_out/grp; mkdir -p $O
 cd $R
