@@ -773,9 +773,8 @@ int vr_sparse_stats(vr_engine* e, const int32_t* ids, int32_t n, int32_t* out_df
 // stream and runs under the dense scan. The k > kFusedMaxK sparse path borrows the dense leg's selection buffers and
 // stays on the main stream.
 // The sparse leg of a hybrid query queued on the lane's auxiliary stream right away (behind the mask on the main
-// stream): what vr_query_text does BEFORE the question's forward pass — the leg needs the words, not the embedding,
-// and its kernel (tens to hundreds of microseconds when the words are common ones) then runs under the encoder
-// instead of beside the dense scan. hybrid_one_query(..., sparse_in_flight = true) joins it.
+// stream): what vr_query_text can do BEFORE the question's forward pass (VR_QUERY_TEXT_AHEAD=1; measured slower than
+// running it beside the dense scan, see there). hybrid_one_query(..., sparse_in_flight = true) joins it.
 static int hybrid_sparse_ahead(vr_engine* e, const int32_t* q_idx, const float* q_val, int nnz, int k, const uint8_t* mask,
                                bool weights_given) {
   VR_CHECK(q_idx && q_val && nnz > 0 && k <= kFusedMaxK && e->n_slices_dev > 0, "no sparse leg to start ahead");
@@ -1476,10 +1475,10 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
   const bool hybrid = !stems.empty();
   if (out_hybrid) *out_hybrid = hybrid ? 1 : 0;
   if (hybrid) {
-    // 3a. hybrid: the lane is taken first and the SPARSE leg started on its auxiliary stream — it needs the words, not
-    //     the embedding, and with common words its kernel is as long as the dense scan — then the forward pass, then
-    //     the dense leg; the sparse leg has run under the encoder by then. Lock order as everywhere: the writers'
-    //     mutex (the encoder), then the shared lock of the lane — a writer takes the same mutex before it publishes.
+    // 3a. hybrid: the lane is taken and the filter mask built BEFORE the forward pass (both used to follow it, on the
+    //     critical path of a second engine call), then the forward pass, then both legs on the lane. Lock order as
+    //     everywhere: the writers' mutex (the encoder), then the shared lock of the lane — a writer takes the same mutex
+    //     before it publishes.
     const int k = limit * 3;  // prefetch_limit, vector_store.py:636
     std::vector<float> ones(stems.size(), 1.0f);
     std::unique_lock<std::mutex> writer(e->wmu);
@@ -1490,7 +1489,11 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
     const uint8_t* mask = nullptr;
     VR_TRY(filter_build_mask(L, filter, &mask));
     const int nnz = static_cast<int>(stems.size());
-    const bool ahead = L->n_slices_dev > 0 && k <= kFusedMaxK;
+    // VR_QUERY_TEXT_AHEAD=1: the sparse leg is queued on the auxiliary stream BEFORE the forward pass (it needs the words,
+    // not the embedding) instead of beside the dense scan. Measured on bench.py's from-text section and NOT the default:
+    // 0.90 ms against 0.815 — the forward pass of one question is 63 small latency-bound kernels, and a sparse kernel that
+    // holds every CU beside them slows each of them (profiles/r03_experiments.md §13).
+    const bool ahead = L->n_slices_dev > 0 && k <= kFusedMaxK && getenv("VR_QUERY_TEXT_AHEAD") && atoi(getenv("VR_QUERY_TEXT_AHEAD")) != 0;
     if (ahead) VR_TRY(hybrid_sparse_ahead(L, stems.data(), ones.data(), nnz, k, mask, false));
     VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
     writer.unlock();
