@@ -1474,9 +1474,11 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
   const int32_t off32[2] = {0, static_cast<int32_t>(wp_off[1])};
   const bool hybrid = !stems.empty();
   if (out_hybrid) *out_hybrid = hybrid ? 1 : 0;
-  if (hybrid) {
-    // 3a. hybrid: the lane is taken and the filter mask built BEFORE the forward pass (both used to follow it, on the
-    //     critical path of a second engine call), then the forward pass, then both legs on the lane. Lock order as
+  // (VR_QUERY_TEXT_LANE_FIRST=0: the forward pass, then vr_search_hybrid as a caller would — the round's earlier form, for A/B timings)
+  const bool lane_first = !(getenv("VR_QUERY_TEXT_LANE_FIRST") && atoi(getenv("VR_QUERY_TEXT_LANE_FIRST")) == 0);
+  if (hybrid && lane_first) {
+    // 3a. hybrid: the lane is taken and the filter mask built BEFORE the forward pass (both used to follow it, in a
+    //     second engine call; worth a hundredth of a millisecond), then the forward pass, then both legs on the lane. Lock order as
     //     everywhere: the writers' mutex (the encoder), then the shared lock of the lane — a writer takes the same mutex
     //     before it publishes.
     const int k = limit * 3;  // prefetch_limit, vector_store.py:636
@@ -1491,7 +1493,7 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
     const int nnz = static_cast<int>(stems.size());
     // VR_QUERY_TEXT_AHEAD=1: the sparse leg is queued on the auxiliary stream BEFORE the forward pass (it needs the words,
     // not the embedding) instead of beside the dense scan. Measured on bench.py's from-text section and NOT the default:
-    // 0.90 ms against 0.815 — the forward pass of one question is 63 small latency-bound kernels, and a sparse kernel that
+    // 0.90-0.92 ms against 0.82-0.84 — the forward pass of one question is 63 small latency-bound kernels, and a sparse kernel that
     // holds every CU beside them slows each of them (profiles/r03_experiments.md §13).
     const bool ahead = L->n_slices_dev > 0 && k <= kFusedMaxK && getenv("VR_QUERY_TEXT_AHEAD") && atoi(getenv("VR_QUERY_TEXT_AHEAD")) != 0;
     if (ahead) VR_TRY(hybrid_sparse_ahead(L, stems.data(), ones.data(), nnz, k, mask, false));
@@ -1511,6 +1513,11 @@ int vr_query_text(vr_engine* e, const vr_wordpiece* tokenizer, const char* dense
   {
     std::lock_guard<std::mutex> writer(e->wmu);
     VR_TRY(encoder_encode(e, wp.data(), off32, 1, VR_MEM_HOST, q_dev, VR_MEM_DEVICE));  // (returns with the stream drained)
+  }
+  if (hybrid) {
+    std::vector<float> ones(stems.size(), 1.0f);
+    return vr_search_hybrid(e, q_dev, VR_MEM_DEVICE, stems.data(), ones.data(), static_cast<int32_t>(stems.size()), limit, sparse_weight,
+                            fusion, filter, out_rows, out_scores, out_from_dense, out_count);
   }
   // no term survived the stop-word filter: the dense-only branch of VectorStoreService.search (vector_store.py:612-617)
   std::vector<float> sc(static_cast<size_t>(limit));
