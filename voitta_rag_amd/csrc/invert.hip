@@ -1792,7 +1792,9 @@ int inv_scan_topk_batch(vr_engine* e, const int32_t* q_off_dev, const int32_t* q
   // many queries: groups of queries share a block per segment and every run of the group's terms is read once
   // (inv_scan_grouped; VR_SPARSE_GROUPED=0 keeps the per-query kernels. The switches are read per call: tests compare the
   // paths, and force an overflow, in one process)
+  // (its candidate regions are nq x segments x >= 16 keys: batches whose regions would pass 2 GB stay on the per-query kernels)
   const bool grouped = pruned && !dbg && allow_grouped && q_off_host && q_ids_host && nq >= 16 && e->n_inv_seg <= 65535 &&
+                       static_cast<int64_t>(nq) * e->n_inv_seg * std::max<int64_t>(kGrpCandCap, std::min<int64_t>(512, 8192 / std::max<int64_t>(e->n_inv_seg, 1))) <= (int64_t{1} << 28) &&
                        !(std::getenv("VR_SPARSE_GROUPED") && atoi(std::getenv("VR_SPARSE_GROUPED")) == 0);
   // ... with the thresholds from a sample of the segments scanned the same way, once there are enough of them
   const bool sampled = grouped && e->n_inv_seg >= 128 && !(std::getenv("VR_SPARSE_GROUP_SAMPLE") && atoi(std::getenv("VR_SPARSE_GROUP_SAMPLE")) == 0);
