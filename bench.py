@@ -870,7 +870,7 @@ def main():
             "ms_per_hybrid_batched_call": None if qps_hybrid is None else round(hyb_dt / batch_reps * 1e3, 3),
             "hybrid_batched_kind": f"{args.queries} hybrid top-10 queries per call (vr_search_hybrid_batch: one batched dense search, one "
                                    "batched sparse search over the inverted index beside it — the grouped scan of csrc/invert.hip: "
-                                   "groups of four queries share a block per segment, thresholds from a sample of the segments — "
+                                   "pairs of queries share a block per segment (four blocks per CU), thresholds from a sample of the segments — "
                                    "min-max fusion of every query on the host threads; host arrays in and out); answers "
                                    "bit-identical to the single-query path (tests/test_batch_hybrid_gpu.py, tests/test_fullsize_gpu.py)",
             "hybrid_batched_sparse_leg": hyb_sparse,

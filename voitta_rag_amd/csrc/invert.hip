@@ -1143,7 +1143,11 @@ __global__ __launch_bounds__(kInvWaves * 64) void sparse_inv_pruned_kernel(
 // segment run together, blockIdx.x = group), against 12 B per posting, query and term before.
 constexpr int kGrpThreads = 512;
 constexpr int kGrpMaxU = 64;     // union terms of a group (the host closes a group before it exceeds this): one per lane
-constexpr int kGrpSlices = 8;    // postings per thread and batch (two batches in flight)
+#ifndef VR_GRP_SLICES
+#define VR_GRP_SLICES 4
+#endif
+constexpr int kGrpSlices = VR_GRP_SLICES;  // postings per thread and batch (two batches in flight). 4, not 8: 56 registers
+                                           // instead of 79 let four blocks of a two-query group share a CU
 constexpr int kGrpPer = 2;       // ... of which a thread adds up this many together
 constexpr int kGrpHdr = 4 + 8;   // ints per group: union size, 3 spare, the (<= 8) queries' numbers (-1: none)
 constexpr int kGrpEnt = 2 + 8;   // ints per union term: slot of the term among the batch's distinct terms, query mask,
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
 
   // the stream of postings, kGrpSlices x 512 positions per batch; batch b + 1 is requested before batch b is added up
   constexpr int kBatch = kGrpSlices * kGrpThreads;
-  uint64_t bk[2][kGrpSlices];
+  uint32_t bk[2][kGrpSlices];  // (the low half of a posting's key: the row sits in its low 12 bits)
   float bv[2][kGrpSlices];
   int bc[2][kGrpSlices];  // the compacted run a position belongs to
   int pc = 0;             // this thread's walk through s_pre (positions only grow)
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
         pdelta = s_lo[pc] - s_pre[pc];
       }
       bc[set][j] = pc;
-      bk[set][j] = kp[ic + pdelta];
+      bk[set][j] = reinterpret_cast<const uint32_t*>(kp + (ic + pdelta))[0];
       bv[set][j] = vp[ic + pdelta];
     }
   };
@@ -1395,7 +1399,7 @@ __global__ __launch_bounds__(kGrpThreads) void sparse_inv_group_kernel(
         r[v] = static_cast<int>(bk[set][j0 + v] & (kInvSegRows - 1));
         val[v] = bv[set][j0 + v];
         mine[v] = (i < total && !(dbg_mode & 1)) ? bc[set][j0 + v] : -1;
-        if ((dbg_mode & 9) && (bk[set][j0 + v] >> 50) == 0x3FFFull && val[v] == 1.25f) acc[0] = val[v];  // (diagnostics: keeps the loads alive)
+        if ((dbg_mode & 9) && bk[set][j0 + v] == 0xFFFFFFFFu && val[v] == 1.25f) acc[0] = val[v];  // (diagnostics: keeps the loads alive)
       }
       if (dbg_mode & 8) continue;
       // every plane's sum of these rows, requested together (a read the posting may not need costs nothing but LDS
@@ -1644,8 +1648,11 @@ int inv_scan_topk(vr_engine* e, const int32_t* q_idx_host, const float* q_val_ho
 // nq x k result keys. *done = false: no query of the batch has terms (nothing was launched). Closes the profiler slot.
 static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const uint8_t* mask_dev, int k, uint64_t* out_keys_dev,
                             const int32_t* q_off_host, const int32_t* q_ids_host, bool sampled, bool* done) {
-  const int want_group = std::getenv("VR_SPARSE_GROUP") ? atoi(std::getenv("VR_SPARSE_GROUP")) : 4;
-  const int group_size = want_group == 2 || want_group == 8 ? want_group : 4;  // (4: two blocks per CU; measured best)
+  // (2: 34 KB of LDS and 56 registers — four blocks = 32 waves per CU, the most a CU holds; measured best: the block is a
+  // chain of dependent phases and other blocks are what hides them — 2.5 ms of kernels per 1000 queries against 3.0 for
+  // groups of 4 at two blocks per CU, although those read fewer postings)
+  const int want_group = std::getenv("VR_SPARSE_GROUP") ? atoi(std::getenv("VR_SPARSE_GROUP")) : 2;
+  const int group_size = want_group == 4 || want_group == 8 ? want_group : 2;
   const int dbg_mode = std::getenv("VR_SPARSE_GROUP_DBG") ? atoi(std::getenv("VR_SPARSE_GROUP_DBG")) : 0;  // timing experiments
   const int64_t n_seg = e->n_inv_seg;
   // keys per (query, segment) region: 32 at a million rows (250 segments), more while the segments are few (a region may
