@@ -1,5 +1,6 @@
 #!/bin/bash
 # occupancy experiment on the grouped sparse scan: posting slots per thread (4 vs 8: registers) x queries per group
+# (build the twin first, here: make -C voitta_rag_amd/csrc slices8; profiles/r03_experiments.md §15)
 set -o pipefail
 R=/root/repo; O=$R/gpurun_out/grp; mkdir -p $O
 cd $R
