@@ -130,7 +130,7 @@ def test_grouped_sparse_batch_keeps_the_exact_answer(small, monkeypatch):
         qs.append((ids, rng.uniform(0.5, 1.5, size=m).astype(np.float32)))
     qs[7] = (np.zeros(0, np.int32), np.zeros(0, np.float32))            # no terms
     qs[11] = (np.array([5], np.int32), np.ones(1, np.float32))         # a term no row carries
-    for group in ("2", "4", "8"):
+    for group in ("2", "3", "4", "8"):
         monkeypatch.setenv("VR_SPARSE_GROUP", group)
         for flt, mask in ((None, live.astype(bool)), (SearchFilter(include_folders=[0, 2, 5]), live.astype(bool) & np.isin(folder, [0, 2, 5]))):
             for k in (1, 10, 30, 64):

@@ -1652,7 +1652,7 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   // chain of dependent phases and other blocks are what hides them — 2.5 ms of kernels per 1000 queries against 3.0 for
   // groups of 4 at two blocks per CU, although those read fewer postings)
   const int want_group = std::getenv("VR_SPARSE_GROUP") ? atoi(std::getenv("VR_SPARSE_GROUP")) : 2;
-  const int group_size = want_group == 4 || want_group == 8 ? want_group : 2;
+  const int group_size = want_group == 3 || want_group == 4 || want_group == 8 ? want_group : 2;
   const int dbg_mode = std::getenv("VR_SPARSE_GROUP_DBG") ? atoi(std::getenv("VR_SPARSE_GROUP_DBG")) : 0;  // timing experiments
   const int64_t n_seg = e->n_inv_seg;
   // keys per (query, segment) region: 32 at a million rows (250 segments), more while the segments are few (a region may
@@ -1708,6 +1708,7 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
     // thresholds: the sampled segments scanned in full, the best key of every 512 rows kept; the k-th best of a query's
     // sample (real rows, real scores) is a lower bound of its final k-th best key
     if (group_size == 2) launch(sparse_inv_group_kernel<2, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
+    else if (group_size == 3) launch(sparse_inv_group_kernel<3, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
     else if (group_size == 4) launch(sparse_inv_group_kernel<4, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
     else launch(sparse_inv_group_kernel<8, true>, n_samp, samp_cand, samp_cnt, kSampCap, seg_stride);
     VR_TRY(topk_select_regions(e, samp_cand, static_cast<int>(n_samp), kSampCap, samp_cnt, nullptr, 0, nullptr, nq, k, out_keys_dev,
@@ -1716,6 +1717,7 @@ static int inv_scan_grouped(vr_engine* e, const float* q_w_dev, int nq, const ui
   hipLaunchKernelGGL(sparse_inv_theta_kernel, dim3(static_cast<unsigned>((lay.n_groups * 8 + 255) / 256)), dim3(256), 0, e->stream, hdr,
                      lay.n_groups, out_keys_dev, k, theta);
   if (group_size == 2) launch(sparse_inv_group_kernel<2, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
+  else if (group_size == 3) launch(sparse_inv_group_kernel<3, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
   else if (group_size == 4) launch(sparse_inv_group_kernel<4, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
   else launch(sparse_inv_group_kernel<8, false>, n_seg, e->sq_cand.p, e->sq_cnt.p, cand_cap, 1);
   prof_end(e);
